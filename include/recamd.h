@@ -1,0 +1,195 @@
+/*
+ * recamd.h — C ABI of the MI355X (gfx950) embedding-lookup + feature-interaction library.
+ *
+ * This is the drop-in boundary for the one hot path of littlemesie/recommend-tf2.0:
+ *     sparse id -> per-field Embedding gather -> concat -> interaction layer
+ * The reference has no FFI/operator registry; its "plugin API" is the tf.keras Layer.call
+ * surface, whose arithmetic lives in TensorFlow ops.  Each entry point below replaces the TF op
+ * sequence of one reference call site (cited as file:line relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain C types only; every pointer except `rec_table_desc*` arrays and the ones marked
+ *     "host" is a DEVICE pointer owned by the caller; the library never allocates on the hot path.
+ *   - all tensors are dense row-major fp32 unless stated; ids are int32 (or fp32 with
+ *     ids_dtype = REC_IDS_F32, truncated toward zero exactly like Keras' Embedding cast).
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and returns immediately; it is re-entrant and keeps no global mutable state except
+ *     the thread-local last-error string.
+ *   - return value: REC_OK or a negative rec_status; nothing throws across this ABI.
+ *   - out-of-range ids never fault: the row reads as zeros (TF-GPU gather semantics) and, if
+ *     `oob_flag` is non-NULL, *oob_flag is set to 1 so the host can raise (TF-CPU semantics).
+ */
+#ifndef RECAMD_H_
+#define RECAMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REC_VERSION 100 /* 0.1.0 */
+
+typedef enum rec_status {
+  REC_OK = 0,
+  REC_EINVAL = -1,   /* NULL pointer / bad enum / bad alignment */
+  REC_ESHAPE = -2,   /* unsupported or inconsistent shape */
+  REC_EOOB = -3,     /* reserved: host-visible out-of-range id (reported through oob_flag) */
+  REC_EHIP = -4,     /* a HIP runtime call failed; see rec_last_error */
+  REC_ENOTIMPL = -5
+} rec_status;
+
+typedef enum rec_ids_dtype { REC_IDS_I32 = 0, REC_IDS_F32 = 1 } rec_ids_dtype;
+
+/* activation applied by Dense-like entry points (Keras activation strings of the reference) */
+typedef enum rec_act {
+  REC_ACT_NONE = 0,
+  REC_ACT_RELU = 1,
+  REC_ACT_SIGMOID = 2,
+  REC_ACT_TANH = 3,
+  REC_ACT_PRELU = 4 /* per-output-channel alpha vector, Keras PReLU (zero-init == relu) */
+} rec_act;
+
+/* One embedding table (one tf.keras.layers.Embedding of the reference).
+ * `base` is a device pointer to a (vocab, dim) row-major fp32 matrix; `out_col` is the first
+ * output column of this field inside the concatenated row (tf.concat(axis=-1) offset). */
+typedef struct rec_table_desc {
+  const float* base;
+  int64_t vocab;
+  int32_t dim;
+  int32_t out_col;
+} rec_table_desc;
+
+#define REC_MAX_TABLES 64 /* per call; callers chunk wider models */
+
+int rec_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+int rec_last_error(char* buf, int n);
+
+/* ---- a1 / K1: per-field Embedding gather + concat -------------------------------------------
+ * Replaces  tf.concat([Embedding_f(sparse_inputs[:, f]) for f], axis=-1)
+ *   src/ctr/deep_fm/model.py:53, dcn/model.py:47, dlrm/model.py:45, autoint/model.py:46,
+ *   din/model.py:62,66,71-72, match/sasrec/model.py:75-79, match/youtube_dnn/model.py:47,53
+ * out[b, tables[f].out_col + c] = tables[f].base[ids[b*ids_stride + f] * dim_f + c]
+ * tables: HOST array of F descriptors (copied into the launch).  ids: (B, F) with row stride
+ * ids_stride (elements).  out: (B, *) with row stride out_stride (floats). */
+int rec_gather_concat_f32(const rec_table_desc* tables, int32_t F,
+                          const void* ids, int32_t ids_dtype, int64_t ids_stride,
+                          int64_t B, float* out, int64_t out_stride,
+                          int32_t* oob_flag, void* stream);
+
+/* ---- a5 / K5: DLRM pairwise-dot interaction ---------------------------------------------------
+ * The reference's DLRM.call (src/ctr/dlrm/model.py:42-54) has no interaction op; this is the
+ * interaction of the paper the file cites (src/ctr/dlrm/model.py:7):
+ *   X = (B, n, D);  Z = X X^T;  out[b, i*(i-1)/2 + j] = Z[b,i,j]  for n > i > j >= 0.
+ * P = n*(n-1)/2 outputs per sample, row stride out_stride. */
+int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_t D,
+                         float* out, int64_t out_stride, void* stream);
+
+/* Fused K1+K5: X rows 0..F-1 are gathered embedding rows (all tables must share dim D), and, when
+ * `dense` != NULL, row F is dense[b, 0:D] (the bottom-MLP output; n = F+1).  Writes
+ * out[b, 0:P] = strictly-lower-triangle dots and, if append_dense, out[b, P:P+D] = dense[b]
+ * (mirrors tf.concat([sparse_part, dense_fea]) of src/ctr/dlrm/model.py:48). */
+int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t F,
+                                const void* ids, int32_t ids_dtype, int64_t ids_stride,
+                                const float* dense, int64_t dense_stride,
+                                int64_t B, float* out, int64_t out_stride,
+                                int32_t append_dense, int32_t* oob_flag, void* stream);
+
+/* ---- a3 / K3: FM layer (DeepFM wide part), src/ctr/layers/modules.py:57-72 -----------------
+ * first: (B, L1) stride first_stride; w: (L1); second: (B, M) stride second_stride.
+ * first_order = sum over THE WHOLE BATCH of first @ w (one scalar, modules.py:65)
+ * out[b] = first_order + 0.5 * ((sum_j second[b,j])^2 - sum_j second[b,j]^2)
+ * workspace: >= rec_fm_layer_workspace_floats(B) floats, caller-owned scratch. */
+int64_t rec_fm_layer_workspace_floats(int64_t B);
+int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_t L1, const float* w,
+                     const float* second, int64_t second_stride, int32_t M,
+                     int64_t B, float* out, float* workspace, void* stream);
+
+/* ---- a4 / K4: DCN CrossNetwork, src/ctr/layers/modules.py:105-112 --------------------------
+ * x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,  l = 0..L-1;  x: (B, dim), w,b: (L, dim) */
+int rec_cross_f32(const float* x, int64_t x_stride, int32_t dim, const float* w, const float* b,
+                  int32_t L, int64_t B, float* out, int64_t out_stride, void* stream);
+
+/* ---- a2 / K2: ctr FM model in gather form, src/ctr/fm/model.py:34-53 ------------------------
+ * The reference builds a (B, nd + sum V_f) one-hot stack and multiplies by w (L,1) and V^T (L,k).
+ * Equivalent gather form (never materialises the one-hot; OOB id -> zero one-hot row):
+ *   lin  = w0 + sum_d dense[b,d] w[d] + sum_f w[off_f + id_f]
+ *   s_k  = sum_d dense[b,d] V[k,d] + sum_f V[k, off_f + id_f]
+ *   q_k  = sum_d dense[b,d]^2 V[k,d]^2 + sum_f V[k, off_f + id_f]^2
+ *   out  = sigmoid(lin + 0.5 * sum_k (s_k^2 - q_k))
+ * V is stored (k, L) row-major exactly like the reference (fm/model.py:29), L = nd + sum vocab.
+ * vocab: HOST int64 array of F field cardinalities. */
+int rec_fm_onehot_f32(const float* dense, int64_t dense_stride, int32_t nd,
+                      const int32_t* ids, int64_t ids_stride, int32_t F, const int64_t* vocab,
+                      const float* w0, const float* w, const float* V, int32_t k,
+                      int64_t B, float* out, void* stream);
+
+/* ---- K11: Dense (+ folded BatchNorm) -----------------------------------------------------------
+ * out = act(x @ W + bias); x: (M, K) stride x_stride, W: (K, N) row-major (Keras kernel layout),
+ * bias: (N) or NULL, alpha: (N) PReLU slopes or NULL.  Used for DNN towers
+ * (src/ctr/layers/modules.py:129-135, src/match/layers/modules.py:21-26), Conv1D(k=1)
+ * (src/match/layers/modules.py:146-149) and the QKV projections. */
+int rec_dense_f32(const float* x, int64_t x_stride, const float* W, const float* bias,
+                  const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
+                  float* out, int64_t out_stride, void* stream);
+
+/* ---- a7 / K6: ctr MultiHeadAttention (AutoInt interacting layer) ----------------------------
+ * src/ctr/layers/modules.py:285-325.  q = act(Xq Wq), k = act(Xk Wk), v = act(Xv Wv) (no bias),
+ * heads (B,H,N,S); P = softmax(q k^T * sqrt(S)) (the reference DIVIDES by S^-0.5, :235-237);
+ * out = merge(P v) (B,N,H*S); if W0 != NULL (use_res): out = relu(out + act(Xv W0)).
+ * Xq/Xk/Xv: (B, N, din);  W*: (din, H*S). */
+int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv, int64_t B, int32_t N,
+                    int32_t din, const float* Wq, const float* Wk, const float* Wv,
+                    const float* W0, int32_t H, int32_t S, int32_t act,
+                    float* out, void* stream);
+
+/* ---- a9 / K7: DIN AttentionLayer pooling, src/ctr/layers/modules.py:144-175 ----------------
+ * score[b,t] = act([q, k_t, q-k_t, q*k_t] . W + bias)  (Dense(hidden_unit=1)),
+ * masked (mask[b,t]==0 -> -4294967296.0; mask==NULL -> ALL scores replaced -> uniform),
+ * softmax over t, out[b] = sum_t P[b,t] v[b,t].  q: (B,d); k,v: (B,T,d); mask: (B,T) fp32;
+ * W: (4d); bias: (1); alpha: (1) for PReLU or NULL. */
+int rec_din_attn_pool_f32(const float* q, const float* k, const float* v, const float* mask,
+                          const float* W, const float* bias, const float* alpha, int32_t act,
+                          int64_t B, int32_t T, int32_t d, float* out, void* stream);
+
+/* ---- a12 / K8: match MultiHeadAttention (row-masked, non-causal, no out-proj) ---------------
+ * src/match/layers/modules.py:115-131 with scaled_dot_product_attention :76-96.
+ * q/k/v: already-projected (B, S, dm) tensors (projection = rec_dense_f32 with bias);
+ * logits = q k^T / sqrt(dm/H); rows with mask[b,s]==0 get every logit = -4294967296.0
+ * (=> uniform 1/S); softmax over keys; out = P v merged to (B,S,dm). mask: (B,S) fp32. */
+int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
+                        int64_t B, int32_t S, int32_t dm, int32_t H, float* out, void* stream);
+
+/* ---- a13 / K9: LayerNormalization(x + r) [* mask], src/match/layers/modules.py:173-185 -----
+ * y = LN(x + r) * gamma + beta over the last axis (biased variance, eps); r may be NULL;
+ * if row_mask != NULL each output row is multiplied by row_mask[row]
+ * (src/match/sasrec/model.py:86). */
+int rec_layernorm_residual_f32(const float* x, const float* r, const float* gamma,
+                               const float* beta, float eps, const float* row_mask,
+                               int64_t rows, int32_t d, float* out, void* stream);
+
+/* ---- a14 / K10: SASRec last-position scores, src/match/sasrec/model.py:88-96 ----------------
+ * out[b, j] = seq_info[b,:] . table[ids[b,j], :]   (fused gather + dot), ids: (B, n) */
+int rec_gather_dot_scores_f32(const float* seq_info, int64_t seq_stride,
+                              const rec_table_desc* table, const int32_t* ids,
+                              int64_t ids_stride, int32_t n, int64_t B,
+                              float* out, int64_t out_stride, int32_t* oob_flag, void* stream);
+
+/* ---- C2: row-sharded lookup helpers (exchange itself = RCCL all-to-all issued by the host) --
+ * Bucket a flat id list by owner rank for cyclic row sharding (owner = id % G, local = id / G):
+ *   counts[g]      = number of ids owned by g             (device int32[G], zeroed by the call)
+ *   perm[i]        = position of id i in the owner-sorted send buffer (stable within owner)
+ *   send_local[p]  = id / G  at sorted position p
+ * n ids (int32).  Deterministic (stable) so results are reproducible. */
+int64_t rec_shard_bucket_workspace_bytes(int64_t n, int32_t G);
+int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, int32_t* counts,
+                         int32_t* perm, int32_t* send_local, void* workspace, void* stream);
+/* out[i, :] = rows[perm[i], :]  (un-permute the returned rows), D floats per row */
+int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,
+                           float* out, int64_t out_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECAMD_H_ */

@@ -1,0 +1,184 @@
+// Thin pybind11 shim over the C ABI (include/recamd.h).  No torch types: device pointers and the
+// HIP stream cross as Python ints (tensor.data_ptr(), torch.cuda.current_stream().cuda_stream).
+// Every function releases the GIL around the (asynchronous) enqueue and raises RuntimeError with
+// rec_last_error() on a negative status, so failures are loud.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "recamd.h"
+
+namespace py = pybind11;
+using ptr_t = uintptr_t;
+using TableTuple = std::tuple<ptr_t, int64_t, int32_t, int32_t>;  // (base, vocab, dim, out_col)
+
+static void check(int rc, const char* fn) {
+  if (rc >= 0) return;
+  char buf[512];
+  rec_last_error(buf, sizeof(buf));
+  throw std::runtime_error(std::string(fn) + " failed (" + std::to_string(rc) + "): " + buf);
+}
+
+static std::vector<rec_table_desc> to_descs(const std::vector<TableTuple>& t) {
+  std::vector<rec_table_desc> d(t.size());
+  for (size_t i = 0; i < t.size(); ++i) {
+    d[i].base = reinterpret_cast<const float*>(std::get<0>(t[i]));
+    d[i].vocab = std::get<1>(t[i]);
+    d[i].dim = std::get<2>(t[i]);
+    d[i].out_col = std::get<3>(t[i]);
+  }
+  return d;
+}
+
+template <typename T>
+static T* P(ptr_t p) { return reinterpret_cast<T*>(p); }
+
+PYBIND11_MODULE(_C, m) {
+  m.doc() = "pybind11 shim over librecamd.so (C ABI, include/recamd.h)";
+  m.def("version", []() { return rec_version(); });
+  m.attr("MAX_TABLES") = REC_MAX_TABLES;
+
+  m.def("gather_concat_f32",
+        [](const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, int64_t ids_stride,
+           int64_t B, ptr_t out, int64_t out_stride, ptr_t oob, ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_concat_f32(d.data(), (int32_t)d.size(), P<const void>(ids), ids_dtype,
+                                      ids_stride, B, P<float>(out), out_stride, P<int32_t>(oob),
+                                      P<void>(stream)),
+                "rec_gather_concat_f32");
+        });
+
+  m.def("pairwise_dot_f32", [](ptr_t x, int64_t B, int n, int D, ptr_t out, int64_t out_stride,
+                               ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_pairwise_dot_f32(P<const float>(x), B, n, D, P<float>(out), out_stride,
+                               P<void>(stream)),
+          "rec_pairwise_dot_f32");
+  });
+
+  m.def("gather_pairwise_dot_f32",
+        [](const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, int64_t ids_stride,
+           ptr_t dense, int64_t dense_stride, int64_t B, ptr_t out, int64_t out_stride,
+           int append_dense, ptr_t oob, ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_pairwise_dot_f32(d.data(), (int32_t)d.size(), P<const void>(ids),
+                                            ids_dtype, ids_stride, P<const float>(dense),
+                                            dense_stride, B, P<float>(out), out_stride,
+                                            append_dense, P<int32_t>(oob), P<void>(stream)),
+                "rec_gather_pairwise_dot_f32");
+        });
+
+  m.def("fm_layer_workspace_floats", [](int64_t B) { return rec_fm_layer_workspace_floats(B); });
+  m.def("fm_layer_f32", [](ptr_t first, int64_t first_stride, int L1, ptr_t w, ptr_t second,
+                           int64_t second_stride, int M, int64_t B, ptr_t out, ptr_t ws,
+                           ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_fm_layer_f32(P<const float>(first), first_stride, L1, P<const float>(w),
+                           P<const float>(second), second_stride, M, B, P<float>(out),
+                           P<float>(ws), P<void>(stream)),
+          "rec_fm_layer_f32");
+  });
+
+  m.def("cross_f32", [](ptr_t x, int64_t x_stride, int dim, ptr_t w, ptr_t b, int L, int64_t B,
+                        ptr_t out, int64_t out_stride, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_cross_f32(P<const float>(x), x_stride, dim, P<const float>(w), P<const float>(b), L,
+                        B, P<float>(out), out_stride, P<void>(stream)),
+          "rec_cross_f32");
+  });
+
+  m.def("fm_onehot_f32",
+        [](ptr_t dense, int64_t dense_stride, int nd, ptr_t ids, int64_t ids_stride,
+           const std::vector<int64_t>& vocab, ptr_t w0, ptr_t w, ptr_t V, int k, int64_t B,
+           ptr_t out, ptr_t stream) {
+          py::gil_scoped_release nogil;
+          check(rec_fm_onehot_f32(P<const float>(dense), dense_stride, nd, P<const int32_t>(ids),
+                                  ids_stride, (int32_t)vocab.size(), vocab.data(),
+                                  P<const float>(w0), P<const float>(w), P<const float>(V), k, B,
+                                  P<float>(out), P<void>(stream)),
+                "rec_fm_onehot_f32");
+        });
+
+  m.def("dense_f32", [](ptr_t x, int64_t x_stride, ptr_t W, ptr_t bias, ptr_t alpha, int act,
+                        int64_t M, int K, int N, ptr_t out, int64_t out_stride, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dense_f32(P<const float>(x), x_stride, P<const float>(W), P<const float>(bias),
+                        P<const float>(alpha), act, M, K, N, P<float>(out), out_stride,
+                        P<void>(stream)),
+          "rec_dense_f32");
+  });
+
+  m.def("mha_ctr_f32", [](ptr_t xq, ptr_t xk, ptr_t xv, int64_t B, int N, int din, ptr_t Wq,
+                          ptr_t Wk, ptr_t Wv, ptr_t W0, int H, int S, int act, ptr_t out,
+                          ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_mha_ctr_f32(P<const float>(xq), P<const float>(xk), P<const float>(xv), B, N, din,
+                          P<const float>(Wq), P<const float>(Wk), P<const float>(Wv),
+                          P<const float>(W0), H, S, act, P<float>(out), P<void>(stream)),
+          "rec_mha_ctr_f32");
+  });
+
+  m.def("din_attn_pool_f32", [](ptr_t q, ptr_t k, ptr_t v, ptr_t mask, ptr_t W, ptr_t bias,
+                                ptr_t alpha, int act, int64_t B, int T, int d, ptr_t out,
+                                ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_din_attn_pool_f32(P<const float>(q), P<const float>(k), P<const float>(v),
+                                P<const float>(mask), P<const float>(W), P<const float>(bias),
+                                P<const float>(alpha), act, B, T, d, P<float>(out),
+                                P<void>(stream)),
+          "rec_din_attn_pool_f32");
+  });
+
+  m.def("mha_rowmask_f32", [](ptr_t q, ptr_t k, ptr_t v, ptr_t mask, int64_t B, int S, int dm,
+                              int H, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_mha_rowmask_f32(P<const float>(q), P<const float>(k), P<const float>(v),
+                              P<const float>(mask), B, S, dm, H, P<float>(out), P<void>(stream)),
+          "rec_mha_rowmask_f32");
+  });
+
+  m.def("layernorm_residual_f32", [](ptr_t x, ptr_t r, ptr_t gamma, ptr_t beta, float eps,
+                                     ptr_t row_mask, int64_t rows, int d, ptr_t out,
+                                     ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_layernorm_residual_f32(P<const float>(x), P<const float>(r), P<const float>(gamma),
+                                     P<const float>(beta), eps, P<const float>(row_mask), rows, d,
+                                     P<float>(out), P<void>(stream)),
+          "rec_layernorm_residual_f32");
+  });
+
+  m.def("gather_dot_scores_f32",
+        [](ptr_t seq_info, int64_t seq_stride, const TableTuple& table, ptr_t ids,
+           int64_t ids_stride, int n, int64_t B, ptr_t out, int64_t out_stride, ptr_t oob,
+           ptr_t stream) {
+          auto d = to_descs({table});
+          py::gil_scoped_release nogil;
+          check(rec_gather_dot_scores_f32(P<const float>(seq_info), seq_stride, d.data(),
+                                          P<const int32_t>(ids), ids_stride, n, B, P<float>(out),
+                                          out_stride, P<int32_t>(oob), P<void>(stream)),
+                "rec_gather_dot_scores_f32");
+        });
+
+  m.def("shard_bucket_workspace_bytes",
+        [](int64_t n, int G) { return rec_shard_bucket_workspace_bytes(n, G); });
+  m.def("shard_bucket_i32", [](ptr_t ids, int64_t n, int G, ptr_t counts, ptr_t perm,
+                               ptr_t send_local, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_bucket_i32(P<const int32_t>(ids), n, G, P<int32_t>(counts), P<int32_t>(perm),
+                               P<int32_t>(send_local), P<void>(ws), P<void>(stream)),
+          "rec_shard_bucket_i32");
+  });
+  m.def("unpermute_rows_f32", [](ptr_t rows, ptr_t perm, int64_t n, int D, ptr_t out,
+                                 int64_t out_stride, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_unpermute_rows_f32(P<const float>(rows), P<const int32_t>(perm), n, D,
+                                 P<float>(out), out_stride, P<void>(stream)),
+          "rec_unpermute_rows_f32");
+  });
+}

@@ -1,0 +1,112 @@
+"""K1 parity: HIP gather+concat vs the numpy oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(dev, vocabs, dims, B, seed, ids_float=False, oob_frac=0.0):
+    rng = np.random.default_rng(seed)
+    tables = [rng.uniform(-0.05, 0.05, size=(v, d)).astype(np.float32) for v, d in zip(vocabs, dims)]
+    ids = np.stack([rng.integers(0, v, size=B) for v in vocabs], axis=1).astype(np.int32)
+    if oob_frac:
+        m = rng.random(ids.shape) < oob_frac
+        ids = np.where(m, np.where(rng.random(ids.shape) < 0.5, -1 - ids, ids + np.array(vocabs)[None, :]), ids).astype(np.int32)
+    if ids_float:
+        idsf = (ids + rng.uniform(0.0, 0.9, size=ids.shape)).astype(np.float32)
+        # float32 rounding may bump to the next integer for large ids: keep ids small in such tests
+        return tables, idsf
+    return tables, ids
+
+
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("B", [1, 37, 1000])
+def test_gather_uniform_bit_exact(dev, D, B):
+    from recamd import ops
+    F = 5
+    vocabs = [11, 1000, 7, 333, 50]
+    tables, ids = _mk(dev, vocabs, [D] * F, B, seed=D * 1000 + B)
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables])
+    out = ops.gather_concat(g, torch.from_numpy(ids).to(dev))
+    torch.cuda.synchronize()
+    exp = ref.gather_concat(tables, ids)
+    assert out.shape == exp.shape
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+def test_gather_mixed_dims_generic_path(dev):
+    from recamd import ops
+    vocabs = [10, 20, 30, 40]
+    dims = [3, 16, 5, 130]
+    tables, ids = _mk(dev, vocabs, dims, 257, seed=7)
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables])
+    out = ops.gather_concat(g, torch.from_numpy(ids).to(dev))
+    exp = ref.gather_concat(tables, ids)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+def test_gather_float_ids_truncate(dev):
+    from recamd import ops
+    vocabs = [100, 50, 70]
+    tables, idsf = _mk(dev, vocabs, [16] * 3, 300, seed=3, ids_float=True)
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables])
+    out = ops.gather_concat(g, torch.from_numpy(idsf).to(dev))
+    exp = ref.gather_concat(tables, idsf)  # oracle truncates toward zero (3.7 -> 3)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize("dims", [[32] * 4, [5, 32, 7, 9]])
+def test_gather_oob_zero_rows_and_flag(dev, dims):
+    from recamd import ops
+    vocabs = [10, 20, 30, 40]
+    tables, ids = _mk(dev, vocabs, dims, 513, seed=11, oob_frac=0.2)
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables])
+    flag = ops.new_oob_flag(dev)
+    out = ops.gather_concat(g, torch.from_numpy(ids).to(dev), oob_flag=flag)
+    exp = ref.gather_concat(tables, ids, oob="zero")
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    assert int(flag.item()) == 1
+    with pytest.raises(IndexError):
+        ref.gather_concat(tables, ids, oob="raise")
+    # in-range ids leave the flag untouched
+    flag.zero_()
+    ops.gather_concat(g, torch.from_numpy(np.zeros_like(ids)).to(dev), oob_flag=flag)
+    assert int(flag.item()) == 0
+
+
+def test_gather_into_wider_buffer_and_strided_ids(dev):
+    from recamd import ops
+    vocabs = [9, 8, 7]
+    tables, ids = _mk(dev, vocabs, [8] * 3, 100, seed=5)
+    # ids live inside a wider (B, 6) matrix (columns 2..4), output inside a (B, 40) buffer at col 16
+    wide_ids = np.full((100, 6), 3, np.int32)
+    wide_ids[:, 2:5] = ids
+    t_ids = torch.from_numpy(wide_ids).to(dev)[:, 2:5]
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables], out_cols=[16, 24, 32])
+    buf = torch.full((100, 40), -1.0, device=dev)
+    ops.gather_concat(g, t_ids, out=buf)
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:, 16:], ref.gather_concat(tables, ids))
+    assert (got[:, :16] == -1).all()
+
+
+def test_gather_nan_inf_payload_bit_exact(dev):
+    from recamd import ops
+    t = np.zeros((4, 8), np.float32)
+    t.view(np.uint32)[1, :] = 0x7FC12345  # NaN payload
+    t[2, :] = np.inf
+    t[3, :] = -0.0
+    ids = np.array([[1], [2], [3], [0], [9]], np.int32)  # last is OOB
+    g = ops.TableGroup([torch.from_numpy(t).to(dev)])
+    out = ops.gather_concat(g, torch.from_numpy(ids).to(dev)).cpu().numpy()
+    exp = ref.gather_concat([t], ids)
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+
+
+def test_cpu_tensor_fails_loudly():
+    from recamd import ops
+    with pytest.raises(RuntimeError):
+        ops.TableGroup([torch.zeros(4, 4)])
