@@ -4,8 +4,6 @@
 #define REC_TODO(name) rec::set_error(name ": not implemented in this build"); return REC_ENOTIMPL
 
 extern "C" {
-int rec_pairwise_dot_f32(const float*, int64_t, int32_t, int32_t, float*, int64_t, void*) { REC_TODO("rec_pairwise_dot_f32"); }
-int rec_gather_pairwise_dot_f32(const rec_table_desc*, int32_t, const void*, int32_t, int64_t, const float*, int64_t, int64_t, float*, int64_t, int32_t, int32_t*, void*) { REC_TODO("rec_gather_pairwise_dot_f32"); }
 int64_t rec_fm_layer_workspace_floats(int64_t) { return 0; }
 int rec_fm_layer_f32(const float*, int64_t, int32_t, const float*, const float*, int64_t, int32_t, int64_t, float*, float*, void*) { REC_TODO("rec_fm_layer_f32"); }
 int rec_cross_f32(const float*, int64_t, int32_t, const float*, const float*, int32_t, int64_t, float*, int64_t, void*) { REC_TODO("rec_cross_f32"); }

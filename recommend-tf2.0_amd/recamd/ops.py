@@ -100,3 +100,52 @@ def gather_concat(group: TableGroup, ids: torch.Tensor, out: Optional[torch.Tens
         C.gather_concat_f32(group.descs[lo:hi], sub.data_ptr(), _ids_dtype(ids), ids.stride(0), B,
                             out.data_ptr(), out.stride(0), _ptr(oob_flag), _stream())
     return out
+
+
+def pairwise_dot(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """DLRM dot interaction: x (B, n, D) -> (B, n(n-1)/2), pairs (i,j), i>j, row-major."""
+    _chk(x, "x")
+    if x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("x: expected contiguous (B, n, D)")
+    B, n, D = x.shape
+    P = n * (n - 1) // 2
+    if out is None:
+        out = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    else:
+        _rows2d(_chk(out, "out"), "out")
+    C.pairwise_dot_f32(x.data_ptr(), B, n, D, out.data_ptr(), out.stride(0), _stream())
+    return out
+
+
+def gather_pairwise_dot(group: TableGroup, ids: torch.Tensor, dense: Optional[torch.Tensor] = None,
+                        append_dense: bool = True, out: Optional[torch.Tensor] = None,
+                        oob_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused K1+K5: gathers the F embedding rows of each sample (never materialised), appends
+    `dense` (B, D) as vector F, and writes the strictly-lower-triangle dots [+ dense]."""
+    ids = _rows2d(_chk(ids, "ids", None), "ids")
+    F = len(group)
+    if ids.shape[1] != F:
+        raise ValueError(f"ids has {ids.shape[1]} columns, model has {F} tables")
+    if len(set(group.dims)) != 1:
+        raise ValueError("gather_pairwise_dot: all tables must share one embed_dim")
+    D = group.dims[0]
+    B = ids.shape[0]
+    n = F + (1 if dense is not None else 0)
+    P = n * (n - 1) // 2
+    if dense is not None:
+        _rows2d(_chk(dense, "dense"), "dense")
+        if dense.shape != (B, D):
+            raise ValueError(f"dense: expected {(B, D)}, got {tuple(dense.shape)}")
+    width = P + (D if (dense is not None and append_dense) else 0)
+    if out is None:
+        out = torch.empty((B, width), dtype=torch.float32, device=ids.device)
+    else:
+        _rows2d(_chk(out, "out"), "out")
+        if out.shape[0] != B or out.shape[1] < width:
+            raise ValueError("out: wrong shape")
+    C.gather_pairwise_dot_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0),
+                              _ptr(dense), dense.stride(0) if dense is not None else 0, B,
+                              out.data_ptr(), out.stride(0),
+                              1 if (dense is not None and append_dense) else 0,
+                              _ptr(oob_flag), _stream())
+    return out
