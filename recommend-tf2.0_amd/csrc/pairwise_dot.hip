@@ -22,6 +22,8 @@
 //     L when bit L of k is set), so only log2(LPR) partials are live next to the 4n tile VGPRs.
 //   * fp32 accumulation order differs from a k-ordered dot (columns are split over lanes, then
 //     tree-reduced); parity tolerance is 1e-5 relative, stated in tests/test_pairwise_dot_gpu.py.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rec {
@@ -237,6 +239,18 @@ __global__ __launch_bounds__(256) void pairdot_generic_kernel(const float* __res
 }
 
 int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const char* who);
+bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, int ids_f32, int n,
+                              const void* ids, int64_t ids_stride, const float* xin,
+                              int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
+                              int append_dense, int* oob, hipStream_t st);
+
+// REC_PAIRDOT_IMPL=mfma selects the matrix-core variant for D = 128 (pairwise_dot_mfma.hip); it is
+// parity-green but currently latency-bound (247 us vs 231 us at 65 536 x 27 x 128, round 1), so
+// the register-tiled VALU kernel below stays the default.  A/B measurements only.
+static bool use_mfma() {
+  const char* e = getenv("REC_PAIRDOT_IMPL");
+  return e && e[0] == 'm';
+}
 
 template <int LPR, int N, bool GATHER, bool HAS_DENSE, int IDS_F32>
 static void launch_pairdot(const TableSet& ts, const void* ids, int64_t ids_stride, const float* xin,
@@ -271,6 +285,12 @@ extern "C" int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TableSet ts{};
   const bool vec_ok = D % 4 == 0 && aligned16(x);
+  if (vec_ok && D == 128 && use_mfma() &&
+      pairdot128_mfma_dispatch(ts, false, false, 0, n, nullptr, 0, x, (int64_t)n * D, B, out,
+                               out_stride, 0, nullptr, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
 #define REC_TRY(LPR_, N_)                                                                         \
   if (vec_ok && D == (LPR_)*4 && n == (N_)) {                                                     \
     launch_pairdot<LPR_, N_, false, false, 0>(ts, nullptr, 0, x, (int64_t)n * D, B, out, out_stride, \
@@ -325,6 +345,13 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D == 128 && use_mfma() &&
+      pairdot128_mfma_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids,
+                               ids_stride, dense, dense_stride, B, out, out_stride, append_dense,
+                               oob_flag, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
 #define REC_TRY(LPR_, N_)                                                                          \
   if (D == (LPR_)*4 && n == (N_)) {                                                                \
     if (dense) {                                                                                   \
