@@ -155,11 +155,14 @@ int rec_din_attn_pool_f32(const float* q, const float* k, const float* v, const 
 
 /* ---- a12 / K8: match MultiHeadAttention (row-masked, non-causal, no out-proj) ---------------
  * src/match/layers/modules.py:115-131 with scaled_dot_product_attention :76-96.
- * q/k/v: already-projected (B, S, dm) tensors (projection = rec_dense_f32 with bias);
- * logits = q k^T / sqrt(dm/H); rows with mask[b,s]==0 get every logit = -4294967296.0
- * (=> uniform 1/S); softmax over keys; out = P v merged to (B,S,dm). mask: (B,S) fp32. */
+ * q: (B, Sq, dm), k/v: (B, Sk, dm) already-projected tensors (projection = rec_dense_f32 with
+ * bias); logits = q k^T / sqrt(dm/H); query rows with mask[b,i]==0 get EVERY logit =
+ * -4294967296.0 (=> uniform 1/Sk); keys are never masked, not causal; softmax over keys;
+ * out = P v merged to (B,Sq,dm).  mask: (B,Sq) fp32.  Sq < Sk serves SASRec's last block, where
+ * only the final query row is consumed (src/match/sasrec/model.py:88). */
 int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
-                        int64_t B, int32_t S, int32_t dm, int32_t H, float* out, void* stream);
+                        int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out,
+                        void* stream);
 
 /* ---- a13 / K9: LayerNormalization(x + r) [* mask], src/match/layers/modules.py:173-185 -----
  * y = LN(x + r) * gamma + beta over the last axis (biased variance, eps); r may be NULL;

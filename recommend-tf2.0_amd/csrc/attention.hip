@@ -1,0 +1,325 @@
+// Attention-family interaction kernels (round-1 versions: exact fp32, LDS-staged, VALU math; the
+// MFMA tilings for the QK^T / PV contractions are the next optimisation step):
+//   K6  rec_mha_ctr_f32        ctr MultiHeadAttention (AutoInt)   src/ctr/layers/modules.py:285-325
+//   K7  rec_din_attn_pool_f32  DIN AttentionLayer pooling         src/ctr/layers/modules.py:144-175
+//   K8  rec_mha_rowmask_f32    match scaled-dot-product attention src/match/layers/modules.py:76-96,115-131
+#include "common.h"
+
+namespace rec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The reference's padding value: python `-2 ** 32 + 1` = -4294967295 -> fp32 -4294967296.0
+__device__ constexpr float kNegPad = -4294967296.0f;
+
+// ------------------------------------------------------------------------------------------------
+// K6 — one workgroup per sample; X, Q, K, V and the H x N x N probabilities live in LDS.
+//   q = act(Xq Wq) etc. (no bias);  P = softmax(q k^T * sqrt(S));  out = merge(P v)
+//   use_res: out = relu(out + act(Xv W0)).
+// LDS floats: max(nx*N*din, H*N*N) + 3*N*HS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mha_ctr_kernel(const float* __restrict__ xq,
+                                                      const float* __restrict__ xk,
+                                                      const float* __restrict__ xv, int N, int din,
+                                                      const float* __restrict__ Wq,
+                                                      const float* __restrict__ Wk,
+                                                      const float* __restrict__ Wv,
+                                                      const float* __restrict__ W0, int H, int S,
+                                                      int act, int nx, int regionA,
+                                                      float* __restrict__ out) {
+  // LDS: region A = the nx (1 if xq==xk==xv, else 3) input copies, later REUSED for the H*N*N
+  // probabilities; region B = Q, K, V.  regionA = max(nx*N*din, H*N*N) floats.
+  extern __shared__ float lds[];
+  const int HS = H * S;
+  float* Xq = lds;
+  float* Xk = nx == 3 ? Xq + N * din : Xq;
+  float* Xv = nx == 3 ? Xk + N * din : Xq;
+  float* Q = lds + regionA;
+  float* Kt = Q + N * HS;
+  float* V = Kt + N * HS;
+  float* Pm = lds;  // [H][N][N], valid after the projection phase
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t xoff = b * (int64_t)N * din;
+  float* orow = out + b * (int64_t)N * HS;
+  for (int e = tid; e < N * din; e += 256) {
+    Xq[e] = xq[xoff + e];
+    if (nx == 3) {
+      Xk[e] = xk[xoff + e];
+      Xv[e] = xv[xoff + e];
+    }
+  }
+  __syncthreads();
+  // projections: thread -> (n, c), c fastest (coalesced W reads).  The residual branch
+  // act(Xv W0) is parked in the output row (same thread re-reads its own element later).
+  for (int e = tid; e < N * HS; e += 256) {
+    const int n = e / HS, c = e - n * HS;
+    float aq = 0.f, ak = 0.f, av = 0.f, ar = 0.f;
+    for (int k = 0; k < din; ++k) {
+      aq = fmaf(Xq[n * din + k], Wq[k * HS + c], aq);
+      ak = fmaf(Xk[n * din + k], Wk[k * HS + c], ak);
+      av = fmaf(Xv[n * din + k], Wv[k * HS + c], av);
+      if (W0) ar = fmaf(Xv[n * din + k], W0[k * HS + c], ar);
+    }
+    Q[e] = act_apply(aq, act, 0.f);
+    Kt[e] = act_apply(ak, act, 0.f);
+    V[e] = act_apply(av, act, 0.f);
+    if (W0) orow[e] = act_apply(ar, act, 0.f);
+  }
+  __syncthreads();
+  // scores + softmax: one thread per (h, i) row.  "/ (S ** -0.5)" == "* sqrt(S)" (modules.py:235-237)
+  const float scale = sqrtf((float)S);
+  for (int r = tid; r < H * N; r += 256) {
+    const int h = r / N, i = r - h * N;
+    float* prow = Pm + (size_t)r * N;
+    float m = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f;
+      for (int k = 0; k < S; ++k) s = fmaf(Q[i * HS + h * S + k], Kt[j * HS + h * S + k], s);
+      s *= scale;
+      prow[j] = s;
+      m = fmaxf(m, s);
+    }
+    float l = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float e = expf(prow[j] - m);
+      prow[j] = e;
+      l += e;
+    }
+    const float inv = 1.f / l;
+    for (int j = 0; j < N; ++j) prow[j] *= inv;
+  }
+  __syncthreads();
+  // out[i][h*S+s] = sum_j P[h][i][j] V[j][h*S+s]  (+ residual)
+  for (int e = tid; e < N * HS; e += 256) {
+    const int i = e / HS, c = e - i * HS;
+    const int h = c / S;
+    const float* prow = Pm + ((size_t)h * N + i) * N;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc = fmaf(prow[j], V[j * HS + c], acc);
+    if (W0) acc = fmaxf(acc + orow[e], 0.f);
+    orow[e] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 — DIN pooling, one wave per sample, online softmax, k/v rows read exactly once (HBM bound:
+// 2*T*d*4 B per sample, or T*d*4 when k == v).  The Dense(1) over [q, k, q-k, q*k] is affine in k:
+//   score_t = act(k_t . (w2 - w3 + q*w4) + q . (w1 + w3) + bias)          (verified)
+// lanes 0..d/4-1 each own 4 columns (d <= 256, d % 4 == 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void din_pool_kernel(const float* __restrict__ q,
+                                                       const float* __restrict__ k,
+                                                       const float* __restrict__ v,
+                                                       const float* __restrict__ mask,
+                                                       const float* __restrict__ W,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ alpha, int act,
+                                                       int has_mask, int64_t B, int T, int d,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int nv = d >> 2;
+  const bool on = lane < nv;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 qv = on ? reinterpret_cast<const f32x4*>(q + b * d)[lane] : z4;
+  const f32x4 w1 = on ? reinterpret_cast<const f32x4*>(W)[lane] : z4;
+  const f32x4 w2 = on ? reinterpret_cast<const f32x4*>(W + d)[lane] : z4;
+  const f32x4 w3 = on ? reinterpret_cast<const f32x4*>(W + 2 * d)[lane] : z4;
+  const f32x4 w4 = on ? reinterpret_cast<const f32x4*>(W + 3 * d)[lane] : z4;
+  const f32x4 u = w2 - w3 + qv * w4;
+  const f32x4 cw = qv * (w1 + w3);
+  const float c0 = wave_sum(cw.x + cw.y + cw.z + cw.w) + bias[0];
+  const float al = alpha ? alpha[0] : 0.f;
+  const bool same = (k == v);
+  const f32x4* pk = reinterpret_cast<const f32x4*>(k + b * (int64_t)T * d);
+  const f32x4* pv = reinterpret_cast<const f32x4*>(v + b * (int64_t)T * d);
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = z4;
+  constexpr int U = 4;
+  for (int t0 = 0; t0 < T; t0 += U) {
+    f32x4 kr[U], vr[U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const int t = t0 + e < T ? t0 + e : T - 1;
+      kr[e] = on ? pk[(int64_t)t * nv + lane] : z4;
+      vr[e] = same ? kr[e] : (on ? pv[(int64_t)t * nv + lane] : z4);
+    }
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      if (t0 + e >= T) break;
+      const f32x4 pr = kr[e] * u;
+      float s = wave_sum(pr.x + pr.y + pr.z + pr.w) + c0;
+      s = act_apply(s, act, al);
+      if (!has_mask || mask[b * T + t0 + e] == 0.f) s = kNegPad;  // modules.py:161-165
+      const float mn = fmaxf(m, s);
+      const float sc = expf(m - mn);  // first step: exp(-inf) = 0
+      const float p = expf(s - mn);
+      acc = acc * sc + vr[e] * p;
+      l = l * sc + p;
+      m = mn;
+    }
+  }
+  if (on) reinterpret_cast<f32x4*>(out + b * d)[lane] = acc * (1.f / l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8 — match attention.  One workgroup per (sample, head, 256-query tile); the head's K and V
+// (Sk x dk each) are staged in LDS once per workgroup and read by broadcast (every thread reads
+// the same K_j / V_j address: conflict-free), one query row per thread, online softmax.
+// Rows whose mask is 0 have EVERY logit replaced by -4294967296.0 (the reference's mask
+// broadcasts along the key axis, modules.py:90-91) => uniform attention over all Sk keys.
+// dk <= 64 (template), q/k/v laid out (B, S, H*dk) exactly as the Dense projections write them.
+// ------------------------------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void mha_rowmask_kernel(const float* __restrict__ q,
+                                                          const float* __restrict__ k,
+                                                          const float* __restrict__ v,
+                                                          const float* __restrict__ mask, int Sq,
+                                                          int Sk, int H, float* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* Ks = lds;                    // [Sk][DK]
+  float* Vs = lds + (size_t)Sk * DK;  // [Sk][DK]
+  const int tid = threadIdx.x;
+  const int qt = blockIdx.x;  // query tile
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int dm = H * DK;
+  const float* kb = k + b * (int64_t)Sk * dm + h * DK;
+  const float* vb = v + b * (int64_t)Sk * dm + h * DK;
+  for (int e = tid; e < Sk * (DK / 4); e += 256) {
+    const int j = e / (DK / 4), c = e - j * (DK / 4);
+    reinterpret_cast<f32x4*>(Ks)[e] = reinterpret_cast<const f32x4*>(kb + (int64_t)j * dm)[c];
+    reinterpret_cast<f32x4*>(Vs)[e] = reinterpret_cast<const f32x4*>(vb + (int64_t)j * dm)[c];
+  }
+  __syncthreads();
+  const int i = qt * 256 + tid;
+  if (i >= Sq) return;
+  const float* qrow = q + (b * Sq + i) * (int64_t)dm + h * DK;
+  f32x4 qr[DK / 4], acc[DK / 4];
+#pragma unroll
+  for (int c = 0; c < DK / 4; ++c) {
+    qr[c] = reinterpret_cast<const f32x4*>(qrow)[c];
+    acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool masked = mask[b * Sq + i] == 0.f;
+  const float inv_sqrt = 1.f / sqrtf((float)DK);
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < Sk; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK / 4; ++c) {
+      const f32x4 kk = reinterpret_cast<const f32x4*>(Ks + (size_t)j * DK)[c];
+      s = fmaf(qr[c].x, kk.x, s);
+      s = fmaf(qr[c].y, kk.y, s);
+      s = fmaf(qr[c].z, kk.z, s);
+      s = fmaf(qr[c].w, kk.w, s);
+    }
+    s = masked ? kNegPad : s * inv_sqrt;
+    const float mn = fmaxf(m, s);
+    const float sc = expf(m - mn);
+    const float p = expf(s - mn);
+    l = l * sc + p;
+    m = mn;
+#pragma unroll
+    for (int c = 0; c < DK / 4; ++c) {
+      const f32x4 vv = reinterpret_cast<const f32x4*>(Vs + (size_t)j * DK)[c];
+      acc[c] = acc[c] * sc + vv * p;
+    }
+  }
+  const float inv = 1.f / l;
+  float* orow = out + (b * Sq + i) * (int64_t)dm + h * DK;
+#pragma unroll
+  for (int c = 0; c < DK / 4; ++c) reinterpret_cast<f32x4*>(orow)[c] = acc[c] * inv;
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv, int64_t B,
+                               int32_t N, int32_t din, const float* Wq, const float* Wk,
+                               const float* Wv, const float* W0, int32_t H, int32_t S, int32_t act,
+                               float* out, void* stream) {
+  const char* who = "rec_mha_ctr_f32";
+  REC_CHECK_ARG(B >= 0 && N >= 1 && din >= 1 && H >= 1 && S >= 1, REC_ESHAPE, "%s: bad shape", who);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_TANH, REC_EINVAL, "%s: bad act %d", who, act);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(xq && xk && xv && Wq && Wk && Wv && out, REC_EINVAL, "%s: NULL pointer", who);
+  const int nx = (xq == xk && xk == xv) ? 1 : 3;
+  size_t regionA = (size_t)nx * N * din;
+  if ((size_t)H * N * N > regionA) regionA = (size_t)H * N * N;
+  regionA = (regionA + 3) & ~(size_t)3;
+  const size_t floats = regionA + (size_t)3 * N * H * S;
+  const size_t lds = floats * sizeof(float);
+  REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: N=%d din=%d H*S=%d needs %zu B of LDS (> 160 KiB)",
+                who, N, din, H * S, lds);
+  REC_CHECK_ARG(B <= 0x7fffffffLL, REC_ESHAPE, "%s: B too large", who);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_ctr_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    REC_CHECK_ARG(e == hipSuccess, REC_EHIP, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mha_ctr_kernel, dim3((unsigned)B), dim3(256), lds, st, xq, xk, xv, N, din, Wq, Wk,
+                     Wv, W0, H, S, act, nx, (int)regionA, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_din_attn_pool_f32(const float* q, const float* k, const float* v, const float* mask,
+                                     const float* W, const float* bias, const float* alpha,
+                                     int32_t act, int64_t B, int32_t T, int32_t d, float* out,
+                                     void* stream) {
+  const char* who = "rec_din_attn_pool_f32";
+  REC_CHECK_ARG(B >= 0 && T >= 1 && d >= 4 && d % 4 == 0 && d <= 256, REC_ESHAPE,
+                "%s: need d %% 4 == 0, 4 <= d <= 256 (got T=%d d=%d)", who, T, d);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_PRELU, REC_EINVAL, "%s: bad act %d", who, act);
+  REC_CHECK_ARG(act != REC_ACT_PRELU || alpha, REC_EINVAL, "%s: PReLU needs alpha", who);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(q && k && v && W && bias && out, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(W) && aligned16(out),
+                REC_EINVAL, "%s: q/k/v/W/out must be 16-B aligned", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(din_pool_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, q, k, v, mask, W,
+                     bias, alpha, act, mask ? 1 : 0, B, T, d, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
+                                   int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H,
+                                   float* out, void* stream) {
+  const char* who = "rec_mha_rowmask_f32";
+  REC_CHECK_ARG(B >= 0 && Sq >= 1 && Sk >= 1 && H >= 1 && dm >= H && dm % H == 0, REC_ESHAPE,
+                "%s: bad shape Sq=%d Sk=%d dm=%d H=%d", who, Sq, Sk, dm, H);
+  const int dk = dm / H;
+  REC_CHECK_ARG(dk == 8 || dk == 16 || dk == 32 || dk == 64, REC_ESHAPE,
+                "%s: head depth %d not in {8,16,32,64}", who, dk);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(q && k && v && mask && out, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), REC_EINVAL,
+                "%s: q/k/v/out must be 16-B aligned", who);
+  REC_CHECK_ARG(B <= 65535, REC_ESHAPE, "%s: B > 65535 per call (chunk the batch)", who);
+  const size_t lds = (size_t)2 * Sk * dk * sizeof(float);
+  REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: Sk=%d dk=%d needs %zu B of LDS", who, Sk, dk, lds);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((Sq + 255) / 256), (unsigned)H, (unsigned)B);
+#define REC_MHA(DK_)                                                                               \
+  case DK_: {                                                                                      \
+    if (lds > 64 * 1024) {                                                                         \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_rowmask_kernel<DK_>),   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+      REC_CHECK_ARG(e == hipSuccess, REC_EHIP, "%s: hipFuncSetAttribute: %s", who,                 \
+                    hipGetErrorString(e));                                                         \
+    }                                                                                              \
+    hipLaunchKernelGGL((mha_rowmask_kernel<DK_>), grid, dim3(256), lds, st, q, k, v, mask, Sq, Sk, \
+                       H, out);                                                                    \
+    break;                                                                                         \
+  }
+  switch (dk) { REC_MHA(8) REC_MHA(16) REC_MHA(32) REC_MHA(64) }
+#undef REC_MHA
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}

@@ -1,0 +1,156 @@
+// K11 — Dense: out = act(x @ W + bias) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact
+// fp32, k-ordered fma chain; there is no xf32/TF32 on gfx950, and 1e-5 parity needs fp32 anyway).
+//
+// Used for the MLP towers (src/ctr/layers/modules.py:129-135 with the BatchNormalization folded
+// into W/bias by the host, src/match/layers/modules.py:21-26), Conv1D(k=1)
+// (src/match/layers/modules.py:146-149) and the attention projections.  Not the headline kernel
+// (SURVEY K11): a plain LDS-tiled 128x128x16 block, 4 waves as 2x2, each wave 2x2 tiles of 32x32.
+// Roofline: fp32 MFMA (157.3 TFLOP/s dense).
+#include "common.h"
+
+namespace rec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA = BM + 4;  // As[k][m]: +4 keeps rows 16-B aligned and staggers banks
+constexpr int LDB = BN + 4;
+
+__global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                         const float* __restrict__ W,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ alpha, int act,
+                                                         int64_t M, int K, int N,
+                                                         float* __restrict__ out, int64_t out_stride) {
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;  // M tiles on grid.x (no 65535 limit)
+  const int n0 = blockIdx.y * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // staging maps: A tile 128 rows x 16 k -> thread (row = tid/2, 8 consecutive k);
+  //               B tile 16 k x 128 n   -> thread (k = tid/16, 8 consecutive n)
+  const int a_row = tid >> 1, a_k = (tid & 1) * 8;
+  const int b_k = tid >> 4, b_n = (tid & 15) * 8;
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    float av[8], bv[8];
+    {
+      const int64_t gm = m0 + a_row;
+      const float* pa = x + gm * x_stride + k0 + a_k;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) av[e] = (gm < M && k0 + a_k + e < K) ? pa[e] : 0.f;
+      const int gk = k0 + b_k;
+      const float* pb = W + (int64_t)gk * N + n0 + b_n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (gk < K && n0 + b_n + e < N) ? pb[e] : 0.f;
+    }
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int e = 0; e < 8; ++e) As[(a_k + e) * LDA + a_row] = av[e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Bs[b_k * LDB + b_n + e] = bv[e];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int kr = kk + (lane >> 5);
+      float a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[kr * LDA + wm * 64 + t * 32 + (lane & 31)];
+        b[t] = Bs[kr * LDB + wn * 64 + t * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= N) continue;
+      const float bb = bias ? bias[col] : 0.f;
+      const float al = alpha ? alpha[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][r] + bb, act, al);
+      }
+    }
+}
+
+// narrow outputs (N <= 8, e.g. the final Dense(1)): one wave per row, lanes stride over K
+template <int NMAX>
+__global__ __launch_bounds__(256) void dense_narrow_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                           const float* __restrict__ W,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ alpha, int act,
+                                                           int64_t M, int K, int N,
+                                                           float* __restrict__ out, int64_t out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float acc[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float xv = x[row * x_stride + k];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+      if (n < N) acc[n] = fmaf(xv, W[(int64_t)k * N + n], acc[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    const float s = wave_sum(acc[n]);
+    if (lane == 0 && n < N)
+      out[row * out_stride + n] = act_apply(s + (bias ? bias[n] : 0.f), act, alpha ? alpha[n] : 0.f);
+  }
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, const float* bias,
+                             const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
+                             float* out, int64_t out_stride, void* stream) {
+  const char* who = "rec_dense_f32";
+  REC_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && x_stride >= K && out_stride >= N, REC_ESHAPE,
+                "%s: bad shape M=%lld K=%d N=%d", who, (long long)M, K, N);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_PRELU, REC_EINVAL, "%s: bad act %d", who, act);
+  REC_CHECK_ARG(act != REC_ACT_PRELU || alpha, REC_EINVAL, "%s: PReLU needs alpha", who);
+  if (M == 0) return REC_OK;
+  REC_CHECK_ARG(x && W && out, REC_EINVAL, "%s: NULL pointer", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (N <= 8) {
+    hipLaunchKernelGGL((dense_narrow_kernel<8>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x,
+                       x_stride, W, bias, alpha, act, M, K, N, out, out_stride);
+  } else {
+    const int64_t gx = (M + BM - 1) / BM;
+    const int gy = (N + BN - 1) / BN;
+    REC_CHECK_ARG(gx <= 0x7fffffffLL && gy <= 65535, REC_ESHAPE, "%s: M or N too large", who);
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    hipLaunchKernelGGL(dense_mfma_kernel, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M,
+                       K, N, out, out_stride);
+  }
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}

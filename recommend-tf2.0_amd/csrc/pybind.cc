@@ -135,11 +135,12 @@ PYBIND11_MODULE(_C, m) {
           "rec_din_attn_pool_f32");
   });
 
-  m.def("mha_rowmask_f32", [](ptr_t q, ptr_t k, ptr_t v, ptr_t mask, int64_t B, int S, int dm,
-                              int H, ptr_t out, ptr_t stream) {
+  m.def("mha_rowmask_f32", [](ptr_t q, ptr_t k, ptr_t v, ptr_t mask, int64_t B, int Sq, int Sk,
+                              int dm, int H, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_mha_rowmask_f32(P<const float>(q), P<const float>(k), P<const float>(v),
-                              P<const float>(mask), B, S, dm, H, P<float>(out), P<void>(stream)),
+                              P<const float>(mask), B, Sq, Sk, dm, H, P<float>(out),
+                              P<void>(stream)),
           "rec_mha_rowmask_f32");
   });
 

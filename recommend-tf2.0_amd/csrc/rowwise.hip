@@ -1,0 +1,481 @@
+// Row-wise interaction kernels (one wave, or a sub-wave lane group, per sample row):
+//   K3  rec_fm_layer_f32          FM layer of DeepFM          src/ctr/layers/modules.py:57-72
+//   K4  rec_cross_f32             DCN CrossNetwork            src/ctr/layers/modules.py:105-112
+//   K2  rec_fm_onehot_f32         ctr FM model, gather form   src/ctr/fm/model.py:34-53
+//   K9  rec_layernorm_residual_f32  LN(x + r) [* row mask]    src/match/layers/modules.py:173-185
+//   K10 rec_gather_dot_scores_f32 SASRec last-position scores src/match/sasrec/model.py:88-96
+// All are HBM-bound streaming reductions: every input element is read exactly once, rows are read
+// with 16-B vector loads where the address allows (scalar head/tail otherwise), reductions are
+// wavefront shuffles, no LDS.
+#include "common.h"
+
+namespace rec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- a row reader that vectorises the 16-B aligned body of an arbitrarily aligned fp32 row ----
+// calls f(value, column) for every column owned by this lane (lane-strided, wave-wide)
+template <typename Fn>
+__device__ __forceinline__ void for_each_in_row(const float* __restrict__ p, int L, int lane, Fn f) {
+  const int mis = (int)((reinterpret_cast<uintptr_t>(p) >> 2) & 3);
+  int head = mis ? 4 - mis : 0;
+  if (head > L) head = L;
+  if (lane < head) f(p[lane], lane);
+  const int nvec = (L - head) >> 2;
+  const f32x4* pv = reinterpret_cast<const f32x4*>(p + head);
+  for (int v = lane; v < nvec; v += 64) {
+    const f32x4 t = pv[v];
+    const int c = head + 4 * v;
+    f(t.x, c);
+    f(t.y, c + 1);
+    f(t.z, c + 2);
+    f(t.w, c + 3);
+  }
+  const int done = head + 4 * nvec;
+  if (done + lane < L) f(p[done + lane], done + lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 — FM layer.  Pass 1: per row  lin_b = first[b].w,  sec_b = 0.5((sum x)^2 - sum x^2);
+// out[b] = sec_b, and each block writes the sum of its rows' lin_b to partial[block].
+// Pass 2: every block re-reduces the (<= 4096) partials in the same fixed order (bit-identical
+// in all blocks, run-to-run reproducible) and adds the batch-global scalar to its rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFmMaxPartials = 4096;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// The second-order term 0.5((sum x)^2 - sum x^2) cancels catastrophically in fp32 (both terms
+// ~ M*var(x), difference ~ 0): the kernel is HBM-bound, so the three running sums are kept in
+// fp64 for free and rounded to fp32 once.
+__global__ __launch_bounds__(256) void fm_layer_rows_kernel(
+    const float* __restrict__ first, int64_t first_stride, int L1, const float* __restrict__ w,
+    const float* __restrict__ second, int64_t second_stride, int M, int64_t B, int rows_per_wave,
+    float* __restrict__ out, double* __restrict__ partial) {
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wv) * rows_per_wave;
+  double lin_acc = 0.0;  // lane-partial of this wave's rows
+  for (int r = 0; r < rows_per_wave; ++r) {
+    const int64_t b = row0 + r;
+    if (b >= B) break;
+    double lin = 0.0, s = 0.0, q = 0.0;
+    for_each_in_row(first + b * first_stride, L1, lane,
+                    [&](float v, int c) { lin = fma((double)v, (double)w[c], lin); });
+    for_each_in_row(second + b * second_stride, M, lane, [&](float v, int) {
+      s += (double)v;
+      q = fma((double)v, (double)v, q);
+    });
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    lin_acc += lin;
+    if (lane == 0) out[b] = (float)(0.5 * (s * s - q));
+  }
+  lin_acc = wave_sum_f64(lin_acc);
+  if (lane == 0) wsum[wv] = lin_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void fm_layer_finish_kernel(const double* __restrict__ partial,
+                                                              int npartial, int64_t B,
+                                                              float* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < npartial; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double first_order = red[0];
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b < B) out[b] = (float)((double)out[b] + first_order);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 — CrossNetwork: x0 and x_l of one row live in VGPRs (VPL float4 per lane, dim <= 256*VPL);
+// per layer one wave-wide dot (shuffle reduce) and one AXPY; w_l / b_l stream from L2.
+// ------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void cross_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                    int dim, const float* __restrict__ w,
+                                                    const float* __restrict__ bv, int L, int64_t B,
+                                                    float* __restrict__ out, int64_t out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int nvec = dim >> 2;
+  f32x4 x0[VPL], xl[VPL];
+  const f32x4* px = reinterpret_cast<const f32x4*>(x + b * x_stride);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int idx = lane + 64 * v;
+    x0[v] = idx < nvec ? px[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    xl[v] = x0[v];
+  }
+  for (int l = 0; l < L; ++l) {
+    const f32x4* pw = reinterpret_cast<const f32x4*>(w + (int64_t)l * dim);
+    const f32x4* pb = reinterpret_cast<const f32x4*>(bv + (int64_t)l * dim);
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int idx = lane + 64 * v;
+      if (idx < nvec) {
+        const f32x4 wv = pw[idx];
+        s = fmaf(xl[v].x, wv.x, s);
+        s = fmaf(xl[v].y, wv.y, s);
+        s = fmaf(xl[v].z, wv.z, s);
+        s = fmaf(xl[v].w, wv.w, s);
+      }
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int idx = lane + 64 * v;
+      if (idx < nvec) {
+        const f32x4 bb = pb[idx];
+        xl[v].x = fmaf(x0[v].x, s, bb.x) + xl[v].x;
+        xl[v].y = fmaf(x0[v].y, s, bb.y) + xl[v].y;
+        xl[v].z = fmaf(x0[v].z, s, bb.z) + xl[v].z;
+        xl[v].w = fmaf(x0[v].w, s, bb.w) + xl[v].w;
+      }
+    }
+  }
+  f32x4* po = reinterpret_cast<f32x4*>(out + b * out_stride);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int idx = lane + 64 * v;
+    if (idx < nvec) po[idx] = xl[v];
+  }
+}
+
+// generic fallback: any dim / alignment; x_l kept in the output row (global), one wave per row
+__global__ __launch_bounds__(256) void cross_generic_kernel(const float* __restrict__ x,
+                                                            int64_t x_stride, int dim,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bv, int L,
+                                                            int64_t B, float* __restrict__ out,
+                                                            int64_t out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* x0 = x + b * x_stride;
+  float* xl = out + b * out_stride;
+  for (int c = lane; c < dim; c += 64) xl[c] = x0[c];
+  for (int l = 0; l < L; ++l) {
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) s = fmaf(xl[c], w[(int64_t)l * dim + c], s);
+    s = wave_sum(s);
+    for (int c = lane; c < dim; c += 64) xl[c] = fmaf(x0[c], s, bv[(int64_t)l * dim + c]) + xl[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 — ctr FM in gather form: one wave per sample, lanes stride over the nd dense + F sparse
+// "active columns" of the never-materialised one-hot stack.
+// ------------------------------------------------------------------------------------------------
+struct FmOffsets {
+  int64_t off[REC_MAX_TABLES];  // first stack column of field f (nd + sum_{g<f} vocab_g)
+  int32_t vocab[REC_MAX_TABLES];
+};
+
+__global__ __launch_bounds__(256) void fm_onehot_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, int nd, const int32_t* __restrict__ ids,
+    int64_t ids_stride, int F, FmOffsets fo, int64_t Ltot, const float* __restrict__ w0,
+    const float* __restrict__ w, const float* __restrict__ V, int k, int64_t B,
+    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  // each lane owns "active columns" a = lane, lane+64, ... of [dense 0..nd) ++ [fields 0..F)
+  float lin = 0.f;
+  float second = 0.f;
+  const int nact = nd + F;
+  // linear term
+  for (int a = lane; a < nact; a += 64) {
+    if (a < nd) {
+      lin = fmaf(dense[b * dense_stride + a], w[a], lin);
+    } else {
+      const int f = a - nd;
+      const int32_t id = ids[b * ids_stride + f];
+      if ((uint32_t)id < (uint32_t)fo.vocab[f]) lin += w[fo.off[f] + id];
+    }
+  }
+  lin = wave_sum(lin);
+  for (int kk = 0; kk < k; ++kk) {
+    const float* Vk = V + (int64_t)kk * Ltot;
+    float s = 0.f, q = 0.f;
+    for (int a = lane; a < nact; a += 64) {
+      float xv = 0.f, vv = 0.f;
+      if (a < nd) {
+        xv = dense[b * dense_stride + a];
+        vv = Vk[a];
+      } else {
+        const int f = a - nd;
+        const int32_t id = ids[b * ids_stride + f];
+        if ((uint32_t)id < (uint32_t)fo.vocab[f]) {
+          xv = 1.f;
+          vv = Vk[fo.off[f] + id];
+        }
+      }
+      const float t = xv * vv;
+      s += t;
+      q = fmaf(t, t, q);  // x^2 v^2 == (x v)^2
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    second += s * s - q;
+  }
+  if (lane == 0) {
+    const float z = w0[0] + lin + 0.5f * second;
+    out[b] = 1.f / (1.f + __expf(-z));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 — y = LN(x + r) * gamma + beta [* row_mask]; one wave per row, d <= 1024
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ r,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ row_mask,
+                                                        int64_t rows, int d,
+                                                        float* __restrict__ out) {
+  constexpr int EPL = 16;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* px = x + row * d;
+  const float* pr = r ? r + row * d : nullptr;
+  float v[EPL];
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = lane + 64 * e;
+    v[e] = c < d ? (px[c] + (pr ? pr[c] : 0.f)) : 0.f;
+    s += v[e];
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = lane + 64 * e;
+    const float t = c < d ? v[e] - mu : 0.f;
+    q = fmaf(t, t, q);
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float inv = 1.f / sqrtf(var + eps);
+  const float m = row_mask ? row_mask[row] : 1.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = lane + 64 * e;
+    if (c < d) out[row * d + c] = ((v[e] - mu) * inv * gamma[c] + beta[c]) * m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10 — out[b, j] = seq_info[b] . table[ids[b, j]]; LPR = d/4 lanes per looked-up row
+// ------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_dot_kernel(
+    const float* __restrict__ seq, int64_t seq_stride, const float* __restrict__ table,
+    int32_t vocab, const int32_t* __restrict__ ids, int64_t ids_stride, int n, int64_t B,
+    float* __restrict__ out, int64_t out_stride, int* __restrict__ oob) {
+  constexpr int RPW = 64 / LPR;  // (b, j) rows per wave pass
+  constexpr int D = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR;
+  const int sl = lane % LPR;
+  const int64_t total = B * (int64_t)n;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t idx = wave * RPW + sub;
+  const bool live = idx < total;
+  const int64_t ii = live ? idx : total - 1;
+  const int64_t b = ii / n;
+  const int j = (int)(ii - b * n);
+  const int32_t id = ids[b * ids_stride + j];
+  const bool ok = (uint32_t)id < (uint32_t)vocab;
+  if (!ok && oob && live) *oob = 1;
+  const f32x4 t = *reinterpret_cast<const f32x4*>(table + (int64_t)(ok ? id : 0) * D + sl * 4);
+  const f32x4 q = *reinterpret_cast<const f32x4*>(seq + b * seq_stride + sl * 4);
+  float acc = t.x * q.x;
+  acc = fmaf(t.y, q.y, acc);
+  acc = fmaf(t.z, q.z, acc);
+  acc = fmaf(t.w, q.w, acc);
+  if (!ok) acc = 0.f;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (live && sl == 0) out[b * out_stride + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void gather_dot_generic_kernel(
+    const float* __restrict__ seq, int64_t seq_stride, const float* __restrict__ table,
+    int32_t vocab, int d, const int32_t* __restrict__ ids, int64_t ids_stride, int n, int64_t B,
+    float* __restrict__ out, int64_t out_stride, int* __restrict__ oob) {
+  const int lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= B * (int64_t)n) return;
+  const int64_t b = idx / n;
+  const int j = (int)(idx - b * n);
+  const int32_t id = ids[b * ids_stride + j];
+  const bool ok = (uint32_t)id < (uint32_t)vocab;
+  if (!ok && oob && lane == 0) *oob = 1;
+  float acc = 0.f;
+  if (ok)
+    for (int c = lane; c < d; c += 64) acc = fmaf(table[(int64_t)id * d + c], seq[b * seq_stride + c], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) out[b * out_stride + j] = acc;
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int64_t rec_fm_layer_workspace_floats(int64_t B) {
+  (void)B;
+  return 2 * kFmMaxPartials + 2;  // kFmMaxPartials fp64 block partials (+ alignment slack)
+}
+
+extern "C" int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_t L1, const float* w,
+                                const float* second, int64_t second_stride, int32_t M, int64_t B,
+                                float* out, float* workspace, void* stream) {
+  const char* who = "rec_fm_layer_f32";
+  REC_CHECK_ARG(first && w && second && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(B >= 0 && L1 >= 1 && M >= 1 && first_stride >= L1 && second_stride >= M, REC_ESHAPE,
+                "%s: bad shape B=%lld L1=%d M=%d", who, (long long)B, L1, M);
+  if (B == 0) return REC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // rows per wave chosen so that the number of block partials stays <= kFmMaxPartials
+  int64_t rpw = (B + (int64_t)4 * kFmMaxPartials - 1) / ((int64_t)4 * kFmMaxPartials);
+  if (rpw < 1) rpw = 1;
+  const int64_t blocks = (B + 4 * rpw - 1) / (4 * rpw);
+  double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 7) & ~(uintptr_t)7);
+  hipLaunchKernelGGL(fm_layer_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, first,
+                     first_stride, L1, w, second, second_stride, M, B, (int)rpw, out, partial);
+  REC_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL(fm_layer_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
+                     partial, (int)blocks, B, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_cross_f32(const float* x, int64_t x_stride, int32_t dim, const float* w,
+                             const float* b, int32_t L, int64_t B, float* out, int64_t out_stride,
+                             void* stream) {
+  const char* who = "rec_cross_f32";
+  REC_CHECK_ARG(x && out && (L == 0 || (w && b)), REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(B >= 0 && dim >= 1 && L >= 0 && x_stride >= dim && out_stride >= dim, REC_ESHAPE,
+                "%s: bad shape B=%lld dim=%d L=%d", who, (long long)B, dim, L);
+  if (B == 0) return REC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+  const bool vec = dim % 4 == 0 && aligned16(x) && aligned16(out) && aligned16(w) && aligned16(b) &&
+                   x_stride % 4 == 0 && out_stride % 4 == 0 && dim <= 4096;
+  if (vec) {
+    const int vpl = (dim / 4 + 63) / 64;
+#define REC_CROSS(V)                                                                            \
+  if (vpl <= V) {                                                                               \
+    hipLaunchKernelGGL((cross_kernel<V>), grid, block, 0, st, x, x_stride, dim, w, b, L, B, out, \
+                       out_stride);                                                             \
+    REC_CHECK_LAUNCH(who);                                                                      \
+    return REC_OK;                                                                              \
+  }
+    REC_CROSS(1) REC_CROSS(2) REC_CROSS(4) REC_CROSS(8) REC_CROSS(13) REC_CROSS(16)
+#undef REC_CROSS
+  }
+  REC_CHECK_ARG(x != out, REC_EINVAL, "%s: generic path cannot run in place", who);
+  hipLaunchKernelGGL(cross_generic_kernel, grid, block, 0, st, x, x_stride, dim, w, b, L, B, out,
+                     out_stride);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_fm_onehot_f32(const float* dense, int64_t dense_stride, int32_t nd,
+                                 const int32_t* ids, int64_t ids_stride, int32_t F,
+                                 const int64_t* vocab, const float* w0, const float* w,
+                                 const float* V, int32_t k, int64_t B, float* out, void* stream) {
+  const char* who = "rec_fm_onehot_f32";
+  REC_CHECK_ARG((nd == 0 || dense) && (F == 0 || (ids && vocab)) && w0 && w && V && out, REC_EINVAL,
+                "%s: NULL pointer", who);
+  REC_CHECK_ARG(B >= 0 && nd >= 0 && F >= 0 && F <= REC_MAX_TABLES && k >= 0, REC_ESHAPE,
+                "%s: bad shape B=%lld nd=%d F=%d k=%d", who, (long long)B, nd, F, k);
+  if (B == 0) return REC_OK;
+  FmOffsets fo;
+  int64_t off = nd;
+  for (int f = 0; f < REC_MAX_TABLES; ++f) {
+    fo.off[f] = off;
+    fo.vocab[f] = 0;
+    if (f < F) {
+      REC_CHECK_ARG(vocab[f] >= 1 && vocab[f] <= 0x7fffffffLL, REC_ESHAPE, "%s: vocab[%d]=%lld", who,
+                    f, (long long)vocab[f]);
+      fo.vocab[f] = (int32_t)vocab[f];
+      off += vocab[f];
+    }
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(fm_onehot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, dense,
+                     dense_stride, nd, ids, ids_stride, F, fo, off, w0, w, V, k, B, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_layernorm_residual_f32(const float* x, const float* r, const float* gamma,
+                                          const float* beta, float eps, const float* row_mask,
+                                          int64_t rows, int32_t d, float* out, void* stream) {
+  const char* who = "rec_layernorm_residual_f32";
+  REC_CHECK_ARG(x && gamma && beta && out, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(rows >= 0 && d >= 1 && d <= 1024, REC_ESHAPE, "%s: rows=%lld d=%d (d <= 1024)", who,
+                (long long)rows, d);
+  if (rows == 0) return REC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, r,
+                     gamma, beta, eps, row_mask, rows, d, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_gather_dot_scores_f32(const float* seq_info, int64_t seq_stride,
+                                         const rec_table_desc* table, const int32_t* ids,
+                                         int64_t ids_stride, int32_t n, int64_t B, float* out,
+                                         int64_t out_stride, int32_t* oob_flag, void* stream) {
+  const char* who = "rec_gather_dot_scores_f32";
+  REC_CHECK_ARG(seq_info && table && table->base && ids && out, REC_EINVAL, "%s: NULL pointer", who);
+  const int d = table->dim;
+  REC_CHECK_ARG(B >= 0 && n >= 1 && d >= 1 && seq_stride >= d && ids_stride >= n && out_stride >= n &&
+                    table->vocab >= 1 && table->vocab <= 0x7fffffffLL,
+                REC_ESHAPE, "%s: bad shape", who);
+  if (B == 0) return REC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = B * (int64_t)n;
+  const int lpr = d / 4;
+  const bool vec = d % 4 == 0 && (lpr & (lpr - 1)) == 0 && lpr <= 64 && aligned16(table->base) &&
+                   aligned16(seq_info) && seq_stride % 4 == 0;
+  if (vec) {
+#define REC_GD(L_)                                                                               \
+  case L_: {                                                                                     \
+    const int64_t waves = (total + (64 / L_) - 1) / (64 / L_);                                   \
+    hipLaunchKernelGGL((gather_dot_kernel<L_>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, \
+                       st, seq_info, seq_stride, table->base, (int32_t)table->vocab, ids,        \
+                       ids_stride, n, B, out, out_stride, oob_flag);                             \
+    break;                                                                                       \
+  }
+    switch (lpr) {
+      REC_GD(1) REC_GD(2) REC_GD(4) REC_GD(8) REC_GD(16) REC_GD(32) REC_GD(64)
+    }
+#undef REC_GD
+  } else {
+    hipLaunchKernelGGL(gather_dot_generic_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st,
+                       seq_info, seq_stride, table->base, (int32_t)table->vocab, d, ids, ids_stride,
+                       n, B, out, out_stride, oob_flag);
+  }
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}

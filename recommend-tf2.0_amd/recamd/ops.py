@@ -43,7 +43,7 @@ def _ids_dtype(ids: torch.Tensor) -> int:
 
 
 def _rows2d(t: torch.Tensor, name: str):
-    if t.dim() != 2 or t.stride(1) != 1:
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
     return t
 
@@ -148,4 +148,214 @@ def gather_pairwise_dot(group: TableGroup, ids: torch.Tensor, dense: Optional[to
                               out.data_ptr(), out.stride(0),
                               1 if (dense is not None and append_dense) else 0,
                               _ptr(oob_flag), _stream())
+    return out
+
+
+def _act_id(act) -> int:
+    if act not in ACT:
+        raise ValueError(f"unsupported activation {act!r} (the reference's default 'prelu' string is not a "
+                         "valid Keras activation either; pass act='prelu' together with an alpha tensor)")
+    return ACT[act]
+
+
+_fm_ws = {}
+
+
+def fm_layer(first: torch.Tensor, second: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """FM layer of DeepFM (src/ctr/layers/modules.py:57-72): first (B,L1), second (B,M), w (L1[,1])
+    -> (B,1).  The first-order term is ONE scalar summed over the whole batch (modules.py:65)."""
+    _rows2d(_chk(first, "first"), "first")
+    _rows2d(_chk(second, "second"), "second")
+    w = _chk(w, "w").reshape(-1)
+    B, L1 = first.shape
+    if second.shape[0] != B or w.numel() != L1 or not w.is_contiguous():
+        raise ValueError("fm_layer: inconsistent shapes")
+    out = torch.empty((B, 1), dtype=torch.float32, device=first.device)
+    key = (first.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _fm_ws.get(key)
+    if ws is None:
+        ws = _fm_ws[key] = torch.empty(C.fm_layer_workspace_floats(B), dtype=torch.float32, device=first.device)
+    C.fm_layer_f32(first.data_ptr(), first.stride(0), L1, w.data_ptr(), second.data_ptr(), second.stride(0),
+                   second.shape[1], B, out.data_ptr(), ws.data_ptr(), _stream())
+    return out
+
+
+def cross_network(x: torch.Tensor, W: torch.Tensor, Bv: torch.Tensor) -> torch.Tensor:
+    """DCN CrossNetwork (src/ctr/layers/modules.py:105-112): x (B,dim); W, Bv (L,dim)."""
+    _rows2d(_chk(x, "x"), "x")
+    _chk(W, "W")
+    _chk(Bv, "Bv")
+    B, dim = x.shape
+    L = W.shape[0]
+    if W.shape != (L, dim) or Bv.shape != (L, dim) or not W.is_contiguous() or not Bv.is_contiguous():
+        raise ValueError("cross_network: W and Bv must be contiguous (L, dim)")
+    out = torch.empty((B, dim), dtype=torch.float32, device=x.device)
+    C.cross_f32(x.data_ptr(), x.stride(0), dim, W.data_ptr(), Bv.data_ptr(), L, B, out.data_ptr(), out.stride(0),
+                _stream())
+    return out
+
+
+def fm_onehot(dense: torch.Tensor, ids: torch.Tensor, vocab: Sequence[int], w0: torch.Tensor, w: torch.Tensor,
+              V: torch.Tensor) -> torch.Tensor:
+    """ctr FM model in gather form (src/ctr/fm/model.py:34-53): dense (B,nd), ids (B,F) int32,
+    w0 (1,), w (L[,1]), V (k,L) -> sigmoid output (B,1)."""
+    _rows2d(_chk(dense, "dense"), "dense")
+    _rows2d(_chk(ids, "ids", torch.int32), "ids")
+    w0, w, V = _chk(w0, "w0"), _chk(w, "w").reshape(-1), _chk(V, "V")
+    B, nd = dense.shape
+    F = ids.shape[1]
+    L = nd + int(sum(vocab))
+    if len(vocab) != F or w.numel() != L or V.dim() != 2 or V.shape[1] != L or not V.is_contiguous():
+        raise ValueError("fm_onehot: inconsistent shapes")
+    out = torch.empty((B, 1), dtype=torch.float32, device=dense.device)
+    C.fm_onehot_f32(dense.data_ptr(), dense.stride(0), nd, ids.data_ptr(), ids.stride(0), [int(v) for v in vocab],
+                    w0.data_ptr(), w.data_ptr(), V.data_ptr(), V.shape[0], B, out.data_ptr(), _stream())
+    return out
+
+
+def dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+          alpha: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Keras Dense on the last axis: act(x @ W + bias); x (..., K) with unit inner stride."""
+    _chk(x, "x")
+    _chk(W, "W")
+    if W.dim() != 2 or not W.is_contiguous():
+        raise ValueError("W: expected contiguous (K, N)")
+    K, N = W.shape
+    if x.shape[-1] != K:
+        raise ValueError(f"dense: x last dim {x.shape[-1]} != K {K}")
+    lead = x.shape[:-1]
+    if x.dim() == 2 and x.stride(1) == 1:
+        x2, xs = x, x.stride(0)
+    else:
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        xs = K
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    else:
+        _rows2d(_chk(out, "out"), "out")
+    if bias is not None:
+        _chk(bias, "bias")
+    if alpha is not None:
+        _chk(alpha, "alpha")
+    C.dense_f32(x2.data_ptr(), xs, W.data_ptr(), _ptr(bias), _ptr(alpha), _act_id(act), M, K, N, out.data_ptr(),
+                out.stride(0), _stream())
+    return out.view(*lead, N) if out.is_contiguous() and out.shape[1] == N else out
+
+
+def mha_ctr(xq: torch.Tensor, xk: torch.Tensor, xv: torch.Tensor, Wq, Wk, Wv, W0=None, head_num=1, head_size=None,
+            act="relu") -> torch.Tensor:
+    """ctr MultiHeadAttention (src/ctr/layers/modules.py:285-325) on (B, N, din) inputs."""
+    for t, nm in ((xq, "xq"), (xk, "xk"), (xv, "xv"), (Wq, "Wq"), (Wk, "Wk"), (Wv, "Wv")):
+        _chk(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f"{nm}: must be contiguous")
+    B, N, din = xq.shape
+    HS = Wq.shape[1]
+    S = head_size if head_size is not None else HS // head_num
+    if HS != head_num * S or Wq.shape[0] != din:
+        raise ValueError("mha_ctr: weight shape mismatch")
+    out = torch.empty((B, N, HS), dtype=torch.float32, device=xq.device)
+    C.mha_ctr_f32(xq.data_ptr(), xk.data_ptr(), xv.data_ptr(), B, N, din, Wq.data_ptr(), Wk.data_ptr(),
+                  Wv.data_ptr(), _ptr(W0), head_num, S, _act_id(act), out.data_ptr(), _stream())
+    return out
+
+
+def din_attention_pool(q, k, v, mask, W, bias, act="sigmoid", alpha=None) -> torch.Tensor:
+    """DIN AttentionLayer (src/ctr/layers/modules.py:144-175), hidden_unit = 1.
+    q (B,d); k,v (B,T,d); mask (B,T) float tensor or None (None => uniform, modules.py:164-165)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (W, "W"), (bias, "bias")):
+        _chk(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f"{nm}: must be contiguous")
+    B, T, d = k.shape
+    if mask is not None:
+        mask = _chk(mask, "mask").contiguous()
+    W = W.reshape(-1)
+    if W.numel() != 4 * d:
+        raise ValueError("din_attention_pool: W must have 4*d elements (Dense(hidden_unit=1))")
+    out = torch.empty((B, d), dtype=torch.float32, device=q.device)
+    C.din_attn_pool_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask), W.data_ptr(), bias.data_ptr(),
+                        _ptr(alpha), _act_id(act), B, T, d, out.data_ptr(), _stream())
+    return out
+
+
+def mha_rowmask(q, k, v, mask, num_heads) -> torch.Tensor:
+    """match scaled_dot_product_attention + head split/merge (src/match/layers/modules.py:76-96,
+    119-130) on projected q (B,Sq,dm), k/v (B,Sk,dm); mask (B,Sq) floats (0 = padded query)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (mask, "mask")):
+        _chk(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f"{nm}: must be contiguous")
+    B, Sq, dm = q.shape
+    Sk = k.shape[1]
+    out = torch.empty((B, Sq, dm), dtype=torch.float32, device=q.device)
+    step = 65535
+    for b0 in range(0, B, step):  # grid.z limit
+        b1 = min(B, b0 + step)
+        C.mha_rowmask_f32(q[b0:b1].data_ptr(), k[b0:b1].data_ptr(), v[b0:b1].data_ptr(), mask[b0:b1].data_ptr(),
+                          b1 - b0, Sq, Sk, dm, num_heads, out[b0:b1].data_ptr(), _stream())
+    return out
+
+
+def layernorm_residual(x, r, gamma, beta, eps, row_mask=None) -> torch.Tensor:
+    """LayerNormalization(x + r) over the last axis [* row_mask] (src/match/layers/modules.py:175,183)."""
+    _chk(x, "x")
+    x = x.contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if r is not None:
+        r = _chk(r, "r").contiguous()
+    if row_mask is not None:
+        row_mask = _chk(row_mask, "row_mask").contiguous()
+    out = torch.empty_like(x)
+    C.layernorm_residual_f32(x.data_ptr(), _ptr(r), _chk(gamma, "gamma").data_ptr(), _chk(beta, "beta").data_ptr(),
+                             float(eps), _ptr(row_mask), rows, d, out.data_ptr(), _stream())
+    return out
+
+
+def gather_dot_scores(seq_info: torch.Tensor, table: torch.Tensor, ids: torch.Tensor,
+                      out: Optional[torch.Tensor] = None, oob_flag=None) -> torch.Tensor:
+    """out[b, j] = seq_info[b] . table[ids[b, j]]  (src/match/sasrec/model.py:90-91, fused gather+dot)."""
+    _rows2d(_chk(seq_info, "seq_info"), "seq_info")
+    _chk(table, "table")
+    _rows2d(_chk(ids, "ids", torch.int32), "ids")
+    B, n = ids.shape
+    if out is None:
+        out = torch.empty((B, n), dtype=torch.float32, device=ids.device)
+    C.gather_dot_scores_f32(seq_info.data_ptr(), seq_info.stride(0),
+                            (table.data_ptr(), int(table.shape[0]), int(table.shape[1]), 0), ids.data_ptr(),
+                            ids.stride(0), n, B, out.data_ptr(), out.stride(0), _ptr(oob_flag), _stream())
+    return out
+
+
+def shard_bucket(ids_flat: torch.Tensor, G: int):
+    """Stable bucketing of a flat int32 id list by owner = id % G.
+    Returns (counts[G] int32, perm[n] int32, send_local[n] int32)."""
+    _chk(ids_flat, "ids", torch.int32)
+    if ids_flat.dim() != 1 or not ids_flat.is_contiguous():
+        raise ValueError("ids: expected a contiguous 1-D tensor")
+    n = ids_flat.numel()
+    dev = ids_flat.device
+    counts = torch.empty(G, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    send_local = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(1, C.shard_bucket_workspace_bytes(n, G)), dtype=torch.uint8, device=dev)
+    C.shard_bucket_i32(ids_flat.data_ptr(), n, G, counts.data_ptr(), perm.data_ptr(), send_local.data_ptr(),
+                       ws.data_ptr(), _stream())
+    return counts, perm, send_local
+
+
+def unpermute_rows(rows: torch.Tensor, perm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = rows[perm[i]]"""
+    _rows2d(_chk(rows, "rows"), "rows")
+    _chk(perm, "perm", torch.int32)
+    n, D = perm.numel(), rows.shape[1]
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=rows.device)
+    if not rows.is_contiguous():
+        raise ValueError("rows: must be contiguous")
+    C.unpermute_rows_f32(rows.data_ptr(), perm.data_ptr(), n, D, out.data_ptr(), out.stride(0), _stream())
     return out

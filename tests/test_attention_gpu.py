@@ -1,0 +1,129 @@
+"""Parity of the attention-family kernels (K6, K7, K8) vs the fp64 numpy oracle (1e-5 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as ref
+from tests.util import close
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("B,N,din,H,S", [(1, 3, 4, 1, 4), (64, 39, 16, 2, 16), (7, 39, 32, 2, 16), (5, 26, 8, 1, 64), (3, 100, 192, 1, 64)])
+@pytest.mark.parametrize("use_res,act", [(False, "relu"), (True, "relu"), (True, None)])
+def test_mha_ctr(dev, B, N, din, H, S, use_res, act):
+    from recamd import ops
+    rng = np.random.default_rng(B * N + din + H)
+    x = (rng.normal(size=(B, N, din)) * 0.5).astype(np.float32)
+    Ws = [(rng.normal(size=(din, H * S)) / np.sqrt(din)).astype(np.float32) for _ in range(4)]
+    tx = T(x, dev)  # one tensor as q, k and v (the layer's single-input form, modules.py:306-309)
+    out = ops.mha_ctr(tx, tx, tx, T(Ws[0], dev), T(Ws[1], dev), T(Ws[2], dev),
+                      T(Ws[3], dev) if use_res else None, H, S, act).cpu().numpy()
+    exp = ref.mha_ctr(x, x, x, Ws[0], Ws[1], Ws[2], Ws[3] if use_res else None, H, S, act)
+    assert close(out, exp)
+
+
+def test_mha_ctr_distinct_qkv(dev):
+    """list-of-3 input form (modules.py:297-300)."""
+    from recamd import ops
+    rng = np.random.default_rng(77)
+    B, N, din, H, S = 9, 11, 8, 2, 4
+    xq, xk, xv = [(rng.normal(size=(B, N, din)) * 0.5).astype(np.float32) for _ in range(3)]
+    Ws = [(rng.normal(size=(din, H * S)) / np.sqrt(din)).astype(np.float32) for _ in range(4)]
+    out = ops.mha_ctr(T(xq, dev), T(xk, dev), T(xv, dev), T(Ws[0], dev), T(Ws[1], dev), T(Ws[2], dev), T(Ws[3], dev),
+                      H, S, "relu").cpu().numpy()
+    assert close(out, ref.mha_ctr(xq, xk, xv, Ws[0], Ws[1], Ws[2], Ws[3], H, S, "relu"))
+
+
+def test_mha_ctr_kat_uniform_and_scale(dev):
+    """Wq = Wk = 0 => uniform attention => out = mean_n act(X Wv); scale is x sqrt(S) (S=16 -> x4):
+    with q=k=one-hot rows the logits are exactly 4 on the diagonal."""
+    from recamd import ops
+    rng = np.random.default_rng(5)
+    B, N, din, S = 2, 6, 16, 16
+    x = rng.normal(size=(B, N, din)).astype(np.float32)
+    Wv = rng.normal(size=(din, S)).astype(np.float32)
+    Z = np.zeros((din, S), np.float32)
+    out = ops.mha_ctr(T(x, dev), T(x, dev), T(x, dev), T(Z, dev), T(Z, dev), T(Wv, dev), None, 1, S, "relu").cpu().numpy()
+    exp = np.maximum(x @ Wv, 0).mean(axis=1, keepdims=True).repeat(N, axis=1)
+    assert close(out, exp)
+    # scale: x = I (N = din = S = 16), Wq = Wk = I, no activation -> logits = 4 * I
+    I = np.eye(16, dtype=np.float32)
+    x2 = I[None]
+    out2 = ops.mha_ctr(T(x2, dev), T(x2, dev), T(x2, dev), T(I, dev), T(I, dev), T(I, dev), None, 1, 16, None).cpu().numpy()
+    p = np.exp(4.0) / (np.exp(4.0) + 15.0)
+    exp2 = np.full((16, 16), (1 - p) / 15.0)
+    np.fill_diagonal(exp2, p)
+    assert close(out2[0], exp2)
+
+
+@pytest.mark.parametrize("B,T_,d", [(1, 1, 4), (64, 100, 192), (9, 10, 16), (33, 37, 64), (5, 100, 256)])
+@pytest.mark.parametrize("act", ["sigmoid", "relu", None, "prelu"])
+@pytest.mark.parametrize("mask_mode", ["lengths", "none", "allzero"])
+def test_din_attention_pool(dev, B, T_, d, act, mask_mode):
+    from recamd import ops
+    rng = np.random.default_rng(B + T_ + d)
+    q = rng.normal(size=(B, d)).astype(np.float32)
+    k = rng.normal(size=(B, T_, d)).astype(np.float32)
+    W = (rng.normal(size=(4 * d, 1)) / np.sqrt(d)).astype(np.float32)
+    b = rng.normal(size=1).astype(np.float32)
+    alpha = np.array([0.25], np.float32) if act == "prelu" else None
+    if mask_mode == "lengths":  # pre-padded histories: zeros first (create_sasrec_dataset-style padding)
+        lens = rng.integers(0, T_ + 1, size=B)
+        mask = (np.arange(T_)[None, :] >= (T_ - lens)[:, None]).astype(np.float32)
+    elif mask_mode == "allzero":
+        mask = np.zeros((B, T_), np.float32)
+    else:
+        mask = None
+    tk = T(k, dev)
+    out = ops.din_attention_pool(T(q, dev), tk, tk, None if mask is None else T(mask, dev), T(W, dev), T(b, dev), act,
+                                 None if alpha is None else T(alpha, dev)).cpu().numpy()
+    exp = ref.din_attention_layer(q, k, k, mask, W, b, act, None if alpha is None else float(alpha[0]))
+    assert close(out, exp)
+    if mask_mode in ("none", "allzero"):  # KAT: uniform attention => mean of v
+        assert close(out, k.astype(np.float64).mean(axis=1))
+
+
+def test_din_attention_pool_distinct_v(dev):
+    from recamd import ops
+    rng = np.random.default_rng(8)
+    B, T_, d = 12, 20, 32
+    q = rng.normal(size=(B, d)).astype(np.float32)
+    k = rng.normal(size=(B, T_, d)).astype(np.float32)
+    v = rng.normal(size=(B, T_, d)).astype(np.float32)
+    W = rng.normal(size=(4 * d, 1)).astype(np.float32) * 0.2
+    b = np.zeros(1, np.float32)
+    mask = (rng.random((B, T_)) > 0.4).astype(np.float32)
+    out = ops.din_attention_pool(T(q, dev), T(k, dev), T(v, dev), T(mask, dev), T(W, dev), T(b, dev), "sigmoid").cpu().numpy()
+    assert close(out, ref.din_attention_layer(q, k, v, mask, W, b, "sigmoid"))
+
+
+@pytest.mark.parametrize("B,Sq,Sk,dm,H", [(1, 1, 1, 8, 1), (8, 200, 200, 64, 1), (3, 10, 10, 64, 2), (5, 300, 300, 64, 4),
+                                          (6, 1, 200, 64, 1), (2, 33, 33, 128, 2)])
+def test_mha_rowmask(dev, B, Sq, Sk, dm, H):
+    from recamd import ops
+    rng = np.random.default_rng(B + Sq + dm + H)
+    q = rng.normal(size=(B, Sq, dm)).astype(np.float32)
+    k = rng.normal(size=(B, Sk, dm)).astype(np.float32)
+    v = rng.normal(size=(B, Sk, dm)).astype(np.float32)
+    mask = (rng.random((B, Sq)) > 0.3).astype(np.float32)
+    out = ops.mha_rowmask(T(q, dev), T(k, dev), T(v, dev), T(mask, dev), H).cpu().numpy()
+
+    def split(t):
+        return np.transpose(t.reshape(B, t.shape[1], H, dm // H), (0, 2, 1, 3)).astype(np.float64)
+
+    m4 = np.tile(mask[:, None, :, None], (1, H, 1, 1))
+    att = ref.sdpa_match(split(q), split(k), split(v), m4)
+    exp = np.transpose(att, (0, 2, 1, 3)).reshape(B, Sq, dm)
+    assert close(out, exp)
+    # KAT: padded query rows attend uniformly over ALL keys (keys are never masked, not causal)
+    padded = mask == 0
+    if padded.any():
+        mean_v = v.astype(np.float64).mean(axis=1)
+        for b in range(B):
+            for i in np.nonzero(padded[b])[0]:
+                assert close(out[b, i], mean_v[b])

@@ -1,0 +1,122 @@
+"""Parity of the row-wise interaction kernels (K2, K3, K4, K9, K10) vs the fp64 numpy oracle.
+Tolerance: |a-b| <= 1e-5 * max(1,|b|) (fp32 logits, BASELINE north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as ref
+from tests.util import close
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("B,L1,M", [(1, 5, 3), (7, 13 + 26 * 8, 26 * 8), (300, 41, 28), (5000, 3341, 3328), (20000, 29, 16)])
+def test_fm_layer(dev, B, L1, M):
+    from recamd import ops
+    rng = np.random.default_rng(B + L1)
+    first = rng.normal(size=(B, L1)).astype(np.float32) * 0.1
+    second = rng.normal(size=(B, M)).astype(np.float32) * 0.1
+    w = (rng.normal(size=(L1, 1)) * 0.05).astype(np.float32)
+    out = ops.fm_layer(T(first, dev), T(second, dev), T(w, dev)).cpu().numpy()
+    assert close(out, ref.fm_layer(first, second, w))
+
+
+def test_fm_layer_kat_and_strided_concat(dev):
+    """x=[1,2,3] => second = 0.5(36-14) = 11; the first-order term is ONE batch scalar.
+    Also exercises the DeepFM layout: first = buf[:, 3:] (unaligned), second = buf[:, 16:]."""
+    from recamd import ops
+    second = np.array([[1, 2, 3], [0, 0, 0]], np.float32)
+    first = np.array([[1, 1], [2, 2]], np.float32)
+    w = np.array([[0.5], [0.25]], np.float32)
+    out = ops.fm_layer(T(first, dev), T(second, dev), T(w, dev)).cpu().numpy()
+    assert np.allclose(out, [[11 + 2.25], [0 + 2.25]])
+    rng = np.random.default_rng(0)
+    buf = rng.normal(size=(64, 16 + 40)).astype(np.float32)
+    tb = T(buf, dev)
+    w2 = rng.normal(size=(53, 1)).astype(np.float32)
+    got = ops.fm_layer(tb[:, 3:], tb[:, 16:], T(w2, dev)).cpu().numpy()
+    assert close(got, ref.fm_layer(buf[:, 3:], buf[:, 16:], w2))
+
+
+@pytest.mark.parametrize("B,dim,L", [(1, 8, 1), (33, 26 * 8, 3), (257, 3328, 3), (100, 4096, 2), (19, 50, 4), (10, 6000, 2), (64, 208, 0)])
+def test_cross_network(dev, B, dim, L):
+    from recamd import ops
+    rng = np.random.default_rng(dim + L)
+    x = (rng.normal(size=(B, dim)) * 0.1).astype(np.float32)
+    W = (rng.normal(size=(L, dim)) * 0.05).astype(np.float32)
+    Bv = (rng.normal(size=(L, dim)) * 0.05).astype(np.float32)
+    out = ops.cross_network(T(x, dev), T(W, dev), T(Bv, dev)).cpu().numpy()
+    assert close(out, ref.cross_network(x, W, Bv))
+
+
+def test_cross_kat_identity(dev):
+    """w=0, b=0 => identity; 1 layer closed form x0 (x0.w) + b + x0."""
+    from recamd import ops
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(5, 16)).astype(np.float32)
+    z = np.zeros((2, 16), np.float32)
+    assert np.array_equal(ops.cross_network(T(x, dev), T(z, dev), T(z, dev)).cpu().numpy(), x)
+    w = rng.normal(size=(1, 16)).astype(np.float32)
+    b = rng.normal(size=(1, 16)).astype(np.float32)
+    exp = x * (x @ w[0])[:, None] + b + x
+    assert close(ops.cross_network(T(x, dev), T(w, dev), T(b, dev)).cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("B,nd,k", [(256, 13, 10), (3, 0, 4), (65, 13, 1), (100, 70, 8)])
+def test_fm_onehot_vs_literal_onehot(dev, B, nd, k):
+    """BASELINE config 1 (FM, batch 256, k=10): gather form on the GPU == the reference's literal
+    one-hot matmul form (oracle), incl. out-of-range ids (zero one-hot row)."""
+    from recamd import ops
+    rng = np.random.default_rng(2020 + B)
+    vocab = [int(v) for v in rng.integers(2, 300, size=26)]
+    L = nd + sum(vocab)
+    dense = rng.random((B, nd)).astype(np.float32)
+    ids = np.stack([rng.integers(0, v, size=B) for v in vocab], axis=1).astype(np.int32)
+    ids[0, 0] = -1
+    ids[B - 1, 3] = vocab[3]
+    w0 = np.array([0.1], np.float32)
+    w = (rng.normal(size=(L, 1)) * 0.05).astype(np.float32)
+    V = (rng.normal(size=(k, L)) * 0.05).astype(np.float32)
+    out = ops.fm_onehot(T(dense, dev), T(ids, dev), vocab, T(w0, dev), T(w, dev), T(V, dev)).cpu().numpy()
+    assert close(out, ref.fm_model_onehot(dense, ids, vocab, w0, w, V))
+    assert close(out, ref.fm_model_gather(dense, ids, vocab, w0, w, V))
+
+
+@pytest.mark.parametrize("rows,d", [(1, 64), (1000, 64), (77, 128), (5, 1000), (33, 7)])
+@pytest.mark.parametrize("with_r,with_mask", [(True, True), (False, False)])
+def test_layernorm_residual(dev, rows, d, with_r, with_mask):
+    from recamd import ops
+    rng = np.random.default_rng(rows + d)
+    x = rng.normal(size=(rows, d)).astype(np.float32)
+    r = rng.normal(size=(rows, d)).astype(np.float32) if with_r else None
+    g = rng.normal(size=d).astype(np.float32)
+    be = rng.normal(size=d).astype(np.float32)
+    m = (rng.random(rows) > 0.3).astype(np.float32) if with_mask else None
+    out = ops.layernorm_residual(T(x, dev), None if r is None else T(r, dev), T(g, dev), T(be, dev), 1e-6,
+                                 None if m is None else T(m, dev)).cpu().numpy()
+    exp = ref.layer_norm((x + (0 if r is None else r)).astype(np.float64), g, be, 1e-6)
+    if m is not None:
+        exp = exp * m[:, None]
+    assert close(out, exp, 2e-5)  # rsqrt(var) amplifies fp32 rounding of the mean for d=7 rows
+
+
+@pytest.mark.parametrize("B,n,d", [(1, 1, 64), (100, 101, 64), (33, 5, 16), (10, 7, 128), (9, 3, 20)])
+def test_gather_dot_scores(dev, B, n, d):
+    from recamd import ops
+    rng = np.random.default_rng(B * n + d)
+    V = 200
+    table = rng.normal(size=(V, d)).astype(np.float32)
+    ids = rng.integers(0, V, size=(B, n)).astype(np.int32)
+    if B > 5:
+        ids[2, 0] = V  # OOB -> score 0
+    seq = rng.normal(size=(B, d)).astype(np.float32)
+    flag = ops.new_oob_flag(dev)
+    out = ops.gather_dot_scores(T(seq, dev), T(table, dev), T(ids, dev), oob_flag=flag).cpu().numpy()
+    emb = ref.embedding_lookup(table.astype(np.float64), ids)
+    exp = np.sum(seq[:, None, :].astype(np.float64) * emb, axis=-1)
+    assert close(out, exp)
+    assert int(flag.item()) == (1 if B > 5 else 0)
