@@ -179,6 +179,19 @@ int rec_gather_dot_scores_f32(const float* seq_info, int64_t seq_stride,
                               int64_t ids_stride, int32_t n, int64_t B,
                               float* out, int64_t out_stride, int32_t* oob_flag, void* stream);
 
+/* ---- small fused epilogues ------------------------------------------------------------------------
+ * out[i] = sigmoid(a[i] + b[i]) (b may be NULL): tf.nn.sigmoid(tf.add(fm_outputs, deep_outputs))
+ * src/ctr/deep_fm/model.py:64 and the final sigmoids of dcn/model.py:56, dlrm/model.py:53. */
+int rec_add_sigmoid_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* out[r, :] = x[r, :] * row_scale[r]:  `att_outputs *= mask`, src/match/sasrec/model.py:82 */
+int rec_scale_rows_f32(const float* x, const float* row_scale, int64_t rows, int32_t d, float* out,
+                       void* stream);
+/* Dice, src/ctr/layers/modules.py:333-337 (inference): p = sigmoid((x - mean) * rsqrt(var + eps));
+ * out = alpha * (1 - p) * x + p * x.  mean/var: (d) moving statistics or NULL (0 / 1);
+ * alpha: device scalar. */
+int rec_dice_f32(const float* x, const float* alpha, const float* mean, const float* var, float eps,
+                 int64_t rows, int32_t d, float* out, void* stream);
+
 /* ---- C2: row-sharded lookup helpers (exchange itself = RCCL all-to-all issued by the host) --
  * Bucket a flat id list by owner rank for cyclic row sharding (owner = id % G, local = id / G):
  *   counts[g]      = number of ids owned by g             (device int32[G], zeroed by the call)

@@ -166,6 +166,25 @@ PYBIND11_MODULE(_C, m) {
                 "rec_gather_dot_scores_f32");
         });
 
+  m.def("add_sigmoid_f32", [](ptr_t a, ptr_t b, int64_t n, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_add_sigmoid_f32(P<const float>(a), P<const float>(b), n, P<float>(out), P<void>(stream)),
+          "rec_add_sigmoid_f32");
+  });
+  m.def("scale_rows_f32", [](ptr_t x, ptr_t sc, int64_t rows, int d, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_scale_rows_f32(P<const float>(x), P<const float>(sc), rows, d, P<float>(out),
+                             P<void>(stream)),
+          "rec_scale_rows_f32");
+  });
+  m.def("dice_f32", [](ptr_t x, ptr_t alpha, ptr_t mean, ptr_t var, float eps, int64_t rows, int d,
+                       ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dice_f32(P<const float>(x), P<const float>(alpha), P<const float>(mean),
+                       P<const float>(var), eps, rows, d, P<float>(out), P<void>(stream)),
+          "rec_dice_f32");
+  });
+
   m.def("shard_bucket_workspace_bytes",
         [](int64_t n, int G) { return rec_shard_bucket_workspace_bytes(n, G); });
   m.def("shard_bucket_i32", [](ptr_t ids, int64_t n, int G, ptr_t counts, ptr_t perm,

@@ -335,9 +335,75 @@ __global__ __launch_bounds__(256) void gather_dot_generic_kernel(
   if (lane == 0) out[b * out_stride + j] = acc;
 }
 
+// ---- tiny elementwise epilogues ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_sigmoid_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b, int64_t n,
+                                                          float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = 1.f / (1.f + expf(-(a[i] + (b ? b[i] : 0.f))));
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ sc, int64_t total,
+                                                         int d, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) out[i] = x[i] * sc[i / d];
+}
+
+__global__ __launch_bounds__(256) void dice_kernel(const float* __restrict__ x,
+                                                   const float* __restrict__ alpha,
+                                                   const float* __restrict__ mean,
+                                                   const float* __restrict__ var, float eps,
+                                                   int64_t total, int d, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % d);
+  const float v = x[i];
+  const float xn = (v - (mean ? mean[c] : 0.f)) / sqrtf((var ? var[c] : 1.f) + eps);
+  const float p = 1.f / (1.f + expf(-xn));
+  out[i] = alpha[0] * (1.f - p) * v + p * v;
+}
+
 }  // namespace rec
 
 using namespace rec;
+
+extern "C" int rec_add_sigmoid_f32(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  const char* who = "rec_add_sigmoid_f32";
+  REC_CHECK_ARG(n >= 0, REC_ESHAPE, "%s: n=%lld", who, (long long)n);
+  if (n == 0) return REC_OK;
+  REC_CHECK_ARG(a && out, REC_EINVAL, "%s: NULL pointer", who);
+  hipLaunchKernelGGL(add_sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a, b, n, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_scale_rows_f32(const float* x, const float* row_scale, int64_t rows, int32_t d,
+                                  float* out, void* stream) {
+  const char* who = "rec_scale_rows_f32";
+  REC_CHECK_ARG(rows >= 0 && d >= 1, REC_ESHAPE, "%s: rows=%lld d=%d", who, (long long)rows, d);
+  if (rows == 0) return REC_OK;
+  REC_CHECK_ARG(x && row_scale && out, REC_EINVAL, "%s: NULL pointer", who);
+  const int64_t total = rows * d;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, row_scale, total, d, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_dice_f32(const float* x, const float* alpha, const float* mean, const float* var,
+                            float eps, int64_t rows, int32_t d, float* out, void* stream) {
+  const char* who = "rec_dice_f32";
+  REC_CHECK_ARG(rows >= 0 && d >= 1, REC_ESHAPE, "%s: rows=%lld d=%d", who, (long long)rows, d);
+  if (rows == 0) return REC_OK;
+  REC_CHECK_ARG(x && alpha && out, REC_EINVAL, "%s: NULL pointer", who);
+  const int64_t total = rows * d;
+  hipLaunchKernelGGL(dice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, alpha, mean, var, eps, total, d, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
 
 extern "C" int64_t rec_fm_layer_workspace_floats(int64_t B) {
   (void)B;

@@ -1,0 +1,52 @@
+"""Mirror of src/ctr/deep_fm/model.py (DeepFM) on the HIP kernels.
+
+Data layout: ONE (B, pad + nd + sum D) buffer holds `embeds = concat([dense, sparse_embed])`
+(deep_fm/model.py:56) without a concat pass: the gather kernel writes the sparse part at a
+16-B aligned column, `embeds` and `sparse_embed` are views of it."""
+import torch
+
+from ctr.layers.modules import DNN, FM
+from recamd import nn, ops
+from recamd.nn import Model, to_device_f32, to_device_ids
+
+
+class DeepFM(Model):
+    def __init__(self, feature_columns, hidden_units=(128, 64, 32), dnn_dropout=0.,
+                 activation='relu', fm_w_reg=1e-6, embed_reg=1e-6):
+        super().__init__()
+        self.dense_feature_columns, self.sparse_feature_columns = feature_columns
+        self.embed_layers = {
+            'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
+                input_dim=feat['feat_num'], input_length=1, output_dim=feat['embed_dim'],
+                embeddings_initializer='random_normal'))                       # deep_fm/model.py:35
+            for i, feat in enumerate(self.sparse_feature_columns)
+        }
+        self.nd = len(self.dense_feature_columns)
+        self.sparse_width = sum(feat['embed_dim'] for feat in self.sparse_feature_columns)
+        self.feature_length = self.nd + self.sparse_width
+        self.embed_dim = self.sparse_feature_columns[0]['embed_dim']
+        self.fm = FM(self.feature_length, fm_w_reg)
+        self.dnn = DNN(hidden_units, activation, dnn_dropout)
+        self.dense = nn.Dense(1, activation=None)
+        self.pad = (-self.nd) % 4
+        cols, c = [], self.pad + self.nd
+        for feat in self.sparse_feature_columns:
+            cols.append(c)
+            c += feat['embed_dim']
+        self.width = (c + 3) // 4 * 4
+        self._group = ops.TableGroup([self.embed_layers['embed_%d' % i].table
+                                      for i in range(len(self.sparse_feature_columns))], out_cols=cols)
+
+    def call(self, inputs, **kwargs):
+        dense_inputs, sparse_inputs = inputs
+        dense_inputs = to_device_f32(dense_inputs, self.device)
+        sparse_inputs = to_device_ids(sparse_inputs, self.device)
+        B = sparse_inputs.shape[0]
+        buf = torch.empty((B, self.width), dtype=torch.float32, device=self.device)
+        buf[:, self.pad:self.pad + self.nd] = dense_inputs                      # dense part of the concat
+        ops.gather_concat(self._group, sparse_inputs, out=buf)                  # :53 (sparse part)
+        embeds = buf[:, self.pad:self.pad + self.feature_length]               # :56
+        sparse_embed = buf[:, self.pad + self.nd:self.pad + self.feature_length]
+        fm_outputs = self.fm([embeds, sparse_embed])                           # :59
+        deep_outputs = self.dense(self.dnn(embeds))                            # :61-62
+        return ops.add_sigmoid(fm_outputs, deep_outputs)                       # :64

@@ -1,0 +1,55 @@
+"""Mirror of src/ctr/dlrm/model.py on the HIP kernels.
+
+The reference's DLRM.call cannot run: it reads `self.dense_inputs` (dlrm/model.py:44) and
+`self.dnn_network` (:50), neither of which exists, and it has no interaction op — it only
+concatenates (:48).  Two modes:
+  interaction='cat' : the INTENDED form of the file: bot_dnn(dense) ; concat[sparse_embed,
+                      dense_fea] ; top_dnn ; Dense(1) ; sigmoid.
+  interaction='dot' : the pairwise-dot interaction of the paper the file cites (:7) — the
+                      BASELINE headline path: one fused gather + pairwise-dot launch; needs
+                      bot_dnn_hidden_units[-1] == embed_dim.  Not reference-pinned (the reference
+                      has no such op); order of the dots: (i,j), i>j, row-major, X = [emb_0..emb_F-1,
+                      dense_fea], output = concat[dots, dense_fea].
+"""
+import torch
+
+from ctr.layers.modules import DNN
+from recamd import nn, ops
+from recamd.nn import Model, to_device_f32, to_device_ids
+
+
+class DLRM(Model):
+    def __init__(self, feature_columns, bot_dnn_hidden_units=[64, 32, 16], top_dnn_hidden_units=[128, 64],
+                 activation='relu', dnn_dropout=0., embed_reg=1e-4, interaction='cat'):
+        super().__init__()
+        if interaction not in ('cat', 'dot'):
+            raise ValueError("interaction must be 'cat' or 'dot'")
+        self.interaction = interaction
+        self.dense_feature_columns, self.sparse_feature_columns = feature_columns
+        self.embed_layers = {
+            'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
+                input_dim=feat['feat_num'], input_length=1, output_dim=feat['embed_dim'],
+                embeddings_initializer='random_uniform'))
+            for i, feat in enumerate(self.sparse_feature_columns)
+        }
+        self.bot_dnn = DNN(bot_dnn_hidden_units, activation, dnn_dropout)
+        self.top_dnn = DNN(top_dnn_hidden_units, activation, dnn_dropout)
+        self.final_dense = nn.Dense(1, activation=None)
+        self._group = ops.TableGroup([self.embed_layers['embed_%d' % i].table
+                                      for i in range(len(self.sparse_feature_columns))])
+        dims = set(self._group.dims)
+        if interaction == 'dot' and (len(dims) != 1 or bot_dnn_hidden_units[-1] != self._group.dims[0]):
+            raise ValueError("interaction='dot' needs one shared embed_dim equal to bot_dnn_hidden_units[-1]")
+
+    def call(self, inputs, **kwargs):
+        dense_inputs, sparse_inputs = inputs
+        dense_inputs = to_device_f32(dense_inputs, self.device)
+        sparse_inputs = to_device_ids(sparse_inputs, self.device)
+        dense_fea = self.bot_dnn(dense_inputs)                                 # intended :44
+        if self.interaction == 'dot':
+            x = ops.gather_pairwise_dot(self._group, sparse_inputs, dense_fea, append_dense=True)
+        else:
+            sparse_embed = ops.gather_concat(self._group, sparse_inputs)       # :45
+            x = torch.cat([sparse_embed, dense_fea], dim=-1)                   # :48
+        top = self.final_dense(self.top_dnn(x))                                # intended :50-51
+        return ops.add_sigmoid(top)                                            # :53

@@ -1,0 +1,75 @@
+"""Mirror of src/match/sasrec/model.py on the HIP kernels.
+
+call([seq (B,S) int32, pos (B,1) int32, neg (B,neg_len) int32]) -> logits (B, 1+neg_len); the
+BCE-style loss of :93-95 is kept in `self.losses[-1]`.  Three DIFFERENT tables seq/pos/neg
+(:75-79), no positional embedding (:74), mask = (seq != 0) (:72), pad rows multiplied by 0 (:82).
+Exact work savings: the last encoder block only encodes the final query row (only x[:, -1] is
+consumed, :88) and the pos/neg lookups are fused with their dot products (K10)."""
+import torch
+
+from match.layers.modules import TransformerEncoder
+from recamd import nn, ops
+from recamd.nn import Model, to_device_ids
+
+
+class SASRec(Model):
+    def __init__(self, user_sparse_feature_columns, item_sparse_feature_columns,
+                 user_dense_feature_columns=(), item_dense_feature_columns=(),
+                 blocks=1, num_heads=1, att_hidden_unit=128, ffn_hidden_unit=128,
+                 dnn_dropout=0., layer_norm_eps=1e-6, seq_len=10, neg_len=100, embed_reg=1e-6,
+                 last_row_only=True):
+        super().__init__()
+        self.seq_len = seq_len
+        self.neg_len = neg_len
+        self.user_sparse_feature_columns = user_sparse_feature_columns
+        self.user_dense_feature_columns = user_dense_feature_columns
+        self.item_sparse_feature_columns = item_sparse_feature_columns
+        self.item_dense_feature_columns = item_dense_feature_columns
+        self.d_model = att_hidden_unit
+        self.user_embed_layers = {
+            'embed_' + str(feat['feat']): self.track('user_embed_' + str(feat['feat']), nn.Embedding(
+                input_dim=feat['feat_num'], input_length=feat['feat_len'], output_dim=feat['embed_dim'],
+                embeddings_initializer='random_uniform'))
+            for feat in self.user_sparse_feature_columns
+        }
+        self.item_embed_layers = {
+            'embed_' + str(feat['feat']): self.track('item_embed_' + str(feat['feat']), nn.Embedding(
+                input_dim=feat['feat_num'], input_length=feat['feat_len'], output_dim=feat['embed_dim'],
+                embeddings_initializer='random_uniform'))
+            for feat in self.item_sparse_feature_columns
+        }
+        self.dropout = nn.Dropout(dnn_dropout)
+        self.encoder_layer = [self.track('encoder_%d' % i, TransformerEncoder(
+            self.d_model, num_heads, ffn_hidden_unit, dnn_dropout, layer_norm_eps)) for i in range(blocks)]
+        self.last_row_only = last_row_only
+        self.losses = []
+        self.embed = None
+
+    def call(self, inputs, **kwargs):
+        seq_inputs, pos_inputs, neg_inputs = [to_device_ids(t, self.device) for t in inputs]
+        B, S = seq_inputs.shape
+        mask = (seq_inputs != 0).to(torch.float32)                                        # :72 (B,S)
+        seq_embed = self.user_embed_layers['embed_seq_item'](seq_inputs)                  # :75 (B,S,d)
+        att_outputs = ops.scale_rows(seq_embed, mask)                                     # :81-82
+        nb = len(self.encoder_layer)
+        seq_info = None
+        for i, block in enumerate(self.encoder_layer):
+            if i == nb - 1 and self.last_row_only:
+                seq_info = block([att_outputs, mask], query_rows=att_outputs[:, -1:, :].contiguous(),
+                                 query_mask=mask[:, -1:].contiguous(),
+                                 out_mask=mask[:, -1].contiguous())[:, 0, :]              # :85-88
+            else:
+                att_outputs = block([att_outputs, mask], out_mask=mask.reshape(-1))        # :85-86
+        if seq_info is None:
+            seq_info = att_outputs[:, -1].contiguous()                                    # :88
+        self.embed = seq_info[:, None, :]
+        logits = torch.empty((B, 1 + neg_inputs.shape[1]), dtype=torch.float32, device=self.device)
+        ops.gather_dot_scores(seq_info, self.user_embed_layers['embed_pos_item'].table, pos_inputs,
+                              out=logits[:, :1])                                          # :77,:90
+        ops.gather_dot_scores(seq_info, self.user_embed_layers['embed_neg_item'].table, neg_inputs,
+                              out=logits[:, 1:])                                          # :79,:91
+        pos_scores, neg_scores = logits[:, :1], logits[:, 1:]
+        losses = torch.mean(-torch.log(torch.sigmoid(pos_scores)) -
+                            torch.log(1 - torch.sigmoid(neg_scores))) / 2                 # :93-94
+        self.losses = [losses]
+        return logits                                                                     # :96

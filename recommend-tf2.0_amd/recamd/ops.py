@@ -359,3 +359,41 @@ def unpermute_rows(rows: torch.Tensor, perm: torch.Tensor, out: Optional[torch.T
         raise ValueError("rows: must be contiguous")
     C.unpermute_rows_f32(rows.data_ptr(), perm.data_ptr(), n, D, out.data_ptr(), out.stride(0), _stream())
     return out
+
+
+def add_sigmoid(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sigmoid(a + b), elementwise (final logits of DeepFM / DCN / DLRM)."""
+    _chk(a, "a")
+    a = a.contiguous()
+    if b is not None:
+        b = _chk(b, "b").contiguous()
+        if b.shape != a.shape:
+            raise ValueError("add_sigmoid: shape mismatch")
+    out = torch.empty_like(a)
+    C.add_sigmoid_f32(a.data_ptr(), _ptr(b), a.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
+    """x[..., :] * row_scale[...]  (SASRec `att_outputs *= mask`)."""
+    _chk(x, "x")
+    x = x.contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    row_scale = _chk(row_scale, "row_scale").contiguous()
+    if row_scale.numel() != rows:
+        raise ValueError("scale_rows: row_scale must have one entry per row")
+    out = torch.empty_like(x)
+    C.scale_rows_f32(x.data_ptr(), row_scale.data_ptr(), rows, d, out.data_ptr(), _stream())
+    return out
+
+
+def dice(x: torch.Tensor, alpha: torch.Tensor, mean=None, var=None, eps: float = 1e-3) -> torch.Tensor:
+    """Dice activation at inference (src/ctr/layers/modules.py:333-337)."""
+    _chk(x, "x")
+    x = x.contiguous()
+    d = x.shape[-1]
+    out = torch.empty_like(x)
+    C.dice_f32(x.data_ptr(), _chk(alpha, "alpha").data_ptr(), _ptr(mean), _ptr(var), float(eps), x.numel() // d, d,
+               out.data_ptr(), _stream())
+    return out
