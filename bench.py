@@ -119,7 +119,8 @@ def main():
         z = np.random.default_rng(1 + rank).zipf(1.05, size=(B, F))
         ids = torch.from_numpy(((z - 1) % V).astype("int32")).to(dev)
     dense = torch.rand((B, D), device=dev, generator=gen_i)
-    out_fused = torch.empty((B, P + D), dtype=torch.float32, device=dev)
+    # (B, 479) result with a 480-float (16-B aligned) row stride, as recamd.ops allocates it
+    out_fused = torch.empty((B, (P + D + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P + D]
     out_gather = torch.empty((B, F * D), dtype=torch.float32, device=dev)
 
     def step_fused():
@@ -191,8 +192,8 @@ def main():
 
     if rank == 0:
         achieved = bytes_step / (dev_ms * 1e-3) / 1e9
-        kern = ("pairdot_kernel<32,27,gather,dense> (fused gather + pairwise dot)"
-                if a.workload == "dlrm_fused" else "gather_uniform_kernel<32>")
+        kern = ("rec::pairdot_kernel<32, 27, true, true, 0, true> (fused gather + pairwise dot, staged stores)"
+                if a.workload == "dlrm_fused" else "rec::gather_uniform_kernel<32, 0>")
         traffic, traffic_src = (pmc_traffic("pairdot_kernel" if a.workload == "dlrm_fused" else
                                             "gather_uniform_kernel", a) if sharded is None else (None, None))
         res = {

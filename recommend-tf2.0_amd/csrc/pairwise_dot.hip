@@ -29,7 +29,11 @@
 namespace rec {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const f32x4 __attribute__((address_space(1)))* grow_t;
+#ifndef REC_PAIRDOT_PACKED
+#define REC_PAIRDOT_PACKED 0
+#endif
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src_lane) {
   uint32_t lo = __shfl((uint32_t)v, src_lane, 64);
@@ -96,8 +100,11 @@ struct PlainSrc {
 
 // LPR lanes per sample, N vectors per sample (compile time), GATHER: rows 0..F-1 come from the
 // tables through ids, row F (if HAS_DENSE) from `dense`.
-template <int LPR, int N, bool GATHER, bool HAS_DENSE, int IDS_F32>
-__global__ __launch_bounds__(256) void pairdot_kernel(
+#ifndef REC_PAIRDOT_MIN_WAVES
+#define REC_PAIRDOT_MIN_WAVES 1
+#endif
+template <int LPR, int N, bool GATHER, bool HAS_DENSE, int IDS_F32, bool OUT_LDS>
+__global__ __launch_bounds__(256, REC_PAIRDOT_MIN_WAVES) void pairdot_kernel(
     TableSet ts, const void* __restrict__ ids, int64_t ids_stride, const float* __restrict__ xin,
     int64_t xin_stride /* plain: sample stride; gather: dense stride */, int64_t B,
     float* __restrict__ out, int64_t out_stride, int append_dense, int* __restrict__ oob) {
@@ -155,16 +162,33 @@ __global__ __launch_bounds__(256) void pairdot_kernel(
   float* orow = out + b * out_stride;
   const int q_of_lane = bitrev<LOG>(sl);  // pair (within a group of LPR) this lane ends up with
 
+  // OUT_LDS: the P (+D) results of a sample are staged in a wave-private LDS row and leave as
+  // 16-B aligned, fully coalesced global_store_dwordx4 (needs a 16-B aligned `out` and
+  // out_stride % 4 == 0, i.e. a padded row stride such as 480 for 479 columns).  The direct path
+  // below scatters 4-B stores at 4-B alignment; on MI355X those cost ~45 us per 65 536 samples
+  // (measured by ablation), the staged form ~free.
+  constexpr int WP = (P + D + 3) / 4 * 4;  // padded row width in LDS (floats)
+  __shared__ __attribute__((aligned(16))) float otile_all[OUT_LDS ? 4 * SPW * WP : 4];
+  float* otile = otile_all + (OUT_LDS ? (wave_in_block * SPW + sw) * WP : 0);
+
   float lvl[LOG > 0 ? LOG : 1];
   int p = 0;  // compile-time after full unrolling
 #pragma unroll
   for (int i = 1; i < N; ++i) {
 #pragma unroll
     for (int j = 0; j < i; ++j) {
+#if REC_PAIRDOT_PACKED
+      // two v_pk_*_f32 + one add instead of four scalar FMAs: a wave that computes alone on its
+      // SIMD issues one VALU op per 4 cycles either way, the packed ops carry twice the work
+      f32x2 c2 = x[i].xy * x[j].xy;
+      c2 = __builtin_elementwise_fma(x[i].zw, x[j].zw, c2);
+      float c = c2.x + c2.y;
+#else
       float c = x[i].x * x[j].x;
       c = fmaf(x[i].y, x[j].y, c);
       c = fmaf(x[i].z, x[j].z, c);
       c = fmaf(x[i].w, x[j].w, c);
+#endif
       const int k = p % LPR;
 #pragma unroll
       for (int L = 0; L < LOG; ++L) {
@@ -176,7 +200,8 @@ __global__ __launch_bounds__(256) void pairdot_kernel(
         }
       }
       if (k == LPR - 1) {  // group complete: lane sl owns pair (p - k) + bitrev(sl)
-        if (live) orow[(p - k) + q_of_lane] = c;
+        if constexpr (OUT_LDS) otile[(p - k) + q_of_lane] = c;
+        else if (live) orow[(p - k) + q_of_lane] = c;
       }
       ++p;
     }
@@ -197,11 +222,34 @@ __global__ __launch_bounds__(256) void pairdot_kernel(
         }
       }
       if (k == LPR - 1) {
-        if (live && q_of_lane < P % LPR) orow[BASE + q_of_lane] = c;
+        if constexpr (OUT_LDS) {
+          if (q_of_lane < P % LPR) otile[BASE + q_of_lane] = c;
+        } else if (live && q_of_lane < P % LPR) {
+          orow[BASE + q_of_lane] = c;
+        }
       }
     }
   }
-  if (append_dense && live) {
+  if constexpr (OUT_LDS) {
+    int W = P;  // columns of this launch
+    if (append_dense) {
+      float* od = otile + P + sl * 4;  // P is odd in general: 4-B aligned LDS writes
+      od[0] = x[N - 1].x;
+      od[1] = x[N - 1].y;
+      od[2] = x[N - 1].z;
+      od[3] = x[N - 1].w;
+      W = P + D;
+    }
+    const int W4 = (W + 3) >> 2;                     // float4 per row, pad columns written as 0
+    if (sl < (W4 << 2) - W) otile[W + sl] = 0.f;
+    // wave-private tile: LDS ops of one wave execute in order, no barrier needed
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(otile);
+    f32x4* o4 = reinterpret_cast<f32x4*>(orow);
+    for (int v = sl; v < W4; v += LPR) {
+      const f32x4 t = t4[v];
+      if (live) o4[v] = t;
+    }
+  } else if (append_dense && live) {
     float* od = orow + P + sl * 4;  // row start is only 4-B aligned in general (P odd)
     od[0] = x[N - 1].x;
     od[1] = x[N - 1].y;
@@ -244,6 +292,15 @@ bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, i
                               int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
                               int append_dense, int* oob, hipStream_t st);
 
+bool pairdot128_w64_dispatch(const TableSet& ts, bool gather, bool has_dense, int ids_f32, int n,
+                             const void* ids, int64_t ids_stride, const float* xin,
+                             int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
+                             int append_dense, int* oob, hipStream_t st);
+static bool use_w64() {
+  const char* e = getenv("REC_PAIRDOT_IMPL");
+  return e && e[0] == 'w';
+}
+
 // REC_PAIRDOT_IMPL=mfma selects the matrix-core variant for D = 128 (pairwise_dot_mfma.hip); it is
 // parity-green but currently latency-bound (247 us vs 231 us at 65 536 x 27 x 128, round 1), so
 // the register-tiled VALU kernel below stays the default.  A/B measurements only.
@@ -259,9 +316,16 @@ static void launch_pairdot(const TableSet& ts, const void* ids, int64_t ids_stri
   constexpr int SPW = 64 / LPR;
   const int64_t waves = (B + SPW - 1) / SPW;
   const int64_t blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32>), dim3((unsigned)blocks),
-                     dim3(256), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
-                     append_dense, oob);
+  const int W = N * (N - 1) / 2 + (append_dense ? LPR * 4 : 0);
+  const bool staged = aligned16(out) && out_stride % 4 == 0 && out_stride >= (W + 3) / 4 * 4;
+  if (staged)
+    hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, true>), dim3((unsigned)blocks),
+                       dim3(256), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
+                       append_dense, oob);
+  else
+    hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, false>), dim3((unsigned)blocks),
+                       dim3(256), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
+                       append_dense, oob);
 }
 
 }  // namespace rec
@@ -285,6 +349,12 @@ extern "C" int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TableSet ts{};
   const bool vec_ok = D % 4 == 0 && aligned16(x);
+  if (vec_ok && D == 128 && use_w64() &&
+      pairdot128_w64_dispatch(ts, false, false, 0, n, nullptr, 0, x, (int64_t)n * D, B, out, out_stride,
+                              0, nullptr, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (vec_ok && D == 128 && use_mfma() &&
       pairdot128_mfma_dispatch(ts, false, false, 0, n, nullptr, 0, x, (int64_t)n * D, B, out,
                                out_stride, 0, nullptr, st)) {
@@ -345,6 +415,12 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D == 128 && use_w64() &&
+      pairdot128_w64_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids, ids_stride,
+                              dense, dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (D == 128 && use_mfma() &&
       pairdot128_mfma_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids,
                                ids_stride, dense, dense_stride, B, out, out_stride, append_dense,

@@ -36,8 +36,8 @@ __device__ __forceinline__ uint64_t shfl64m(uint64_t v, int src_lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-template <int N, bool GATHER, bool HAS_DENSE, int IDS_F32>
-__global__ __launch_bounds__(64) void pairdot128_mfma_kernel(
+template <int N, bool GATHER, bool HAS_DENSE, int IDS_F32, bool PREFETCH>
+__global__ __launch_bounds__(256, PREFETCH ? 2 : 3) void pairdot128_mfma_kernel(
     TableSet ts, const void* __restrict__ ids, int64_t ids_stride, const float* __restrict__ xin,
     int64_t xin_stride, int64_t B, float* __restrict__ out, int64_t out_stride, int append_dense,
     int* __restrict__ oob) {
@@ -50,9 +50,11 @@ __global__ __launch_bounds__(64) void pairdot128_mfma_kernel(
   static_assert(N >= 2 && N <= 32, "N in [2,32]");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  u32x4* lds = reinterpret_cast<u32x4*>(lds_raw);  // [NR][32] chunks of 16 B
+  // each wave of the workgroup owns a private [NR][32] x 16-B image: no barriers anywhere
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32x4* lds = reinterpret_cast<u32x4*>(lds_raw) + wave_in_block * (NR * 32);
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int half = lane >> 5;
   const int sl = lane & 31;
 
@@ -87,16 +89,17 @@ __global__ __launch_bounds__(64) void pairdot128_mfma_kernel(
     }
   };
 
-  const int64_t nwaves = gridDim.x;
-  int64_t b = blockIdx.x;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
   if (b >= B) return;
-  request(b);
+  if constexpr (PREFETCH) request(b);
 
   // MFMA operand addressing (constant per lane)
   const int trow = lane & 15;
   const int g = lane >> 4;
 
   for (; b < B; b += nwaves) {
+    if constexpr (!PREFETCH) request(b);
     // ---- staging registers -> swizzled LDS image
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -121,11 +124,18 @@ __global__ __launch_bounds__(64) void pairdot128_mfma_kernel(
     }
 
     // ---- prefetch the next sample while the matrix cores work
-    const int64_t bn = b + nwaves;
-    if (bn < B) request(bn);
+    if constexpr (PREFETCH) {
+      const int64_t bn = b + nwaves;
+      if (bn < B) request(bn);
+    }
 
     // ---- Z tiles: z00 = X0 X0^T, z10 = X1 X0^T, z11 = X1 X1^T
     f32x4 z00 = {0.f, 0.f, 0.f, 0.f}, z10 = z00, z11 = z00;
+    const int dbg = append_dense >> 8;
+    if (dbg & 1) {  // ablation: no MFMA
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { z00 += xa[0][c]; if constexpr (NT == 2) z11 += xa[1][c]; }
+    } else
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
 #pragma unroll
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(64) void pairdot128_mfma_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i0 = 4 * g + e;
+      if (dbg & 2) { if (z00[e] == 1234.5f) orow[0] = z00[e] + z10[e] + z11[e]; continue; }
       if (i0 < N && j0 < i0) orow[i0 * (i0 - 1) / 2 + j0] = z00[e];
       if constexpr (NT == 2) {
         const int i1 = 16 + i0;
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(64) void pairdot128_mfma_kernel(
       }
     }
     if constexpr (HAS_DENSE) {
-      if (append_dense && half == ((N - 1) & 1)) {
+      if ((append_dense & 0xff) && half == ((N - 1) & 1)) {
         float* od = orow + P + sl * 4;  // only 4-B aligned in general (P odd)
         od[0] = __uint_as_float(dense_regs.x);
         od[1] = __uint_as_float(dense_regs.y);
@@ -175,13 +186,28 @@ static int launch_mfma(const TableSet& ts, const void* ids, int64_t ids_stride, 
   constexpr int NR = 2 * ((N + 1) / 2);
   const size_t lds = (size_t)NR * 512;
   // persistent waves: as many as the LDS lets reside (160 KiB / CU), capped by the batch
-  int per_cu = (int)((160 * 1024) / lds) < 16 ? (int)((160 * 1024) / lds) : 16;
-  if (const char* e = getenv("REC_PAIRDOT_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  int wpb = 2;  // waves per workgroup
+  if (const char* e = getenv("REC_PAIRDOT_WPB")) wpb = atoi(e) > 0 ? atoi(e) : wpb;
+  int per_cu = (int)((160 * 1024) / (lds * wpb));  // workgroups per CU by LDS
+  if (const char* e = getenv("REC_PAIRDOT_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) / wpb : per_cu;
   int64_t grid = (int64_t)256 * per_cu;
-  if (grid > B) grid = B;
-  hipLaunchKernelGGL((pairdot128_mfma_kernel<N, GATHER, HAS_DENSE, IDS_F32>), dim3((unsigned)grid),
-                     dim3(64), lds, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
-                     append_dense, oob);
+  if (grid * wpb > B) grid = (B + wpb - 1) / wpb;
+  const size_t lds_block = lds * wpb;
+  if (lds_block > 64 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(pairdot128_mfma_kernel<N, GATHER, HAS_DENSE, IDS_F32, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(pairdot128_mfma_kernel<N, GATHER, HAS_DENSE, IDS_F32, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
+  }
+  const char* pf = getenv("REC_PAIRDOT_PREFETCH");
+  if (pf && pf[0] == '1')
+    hipLaunchKernelGGL((pairdot128_mfma_kernel<N, GATHER, HAS_DENSE, IDS_F32, true>), dim3((unsigned)grid),
+                       dim3(64 * wpb), lds_block, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
+                       append_dense, oob);
+  else
+    hipLaunchKernelGGL((pairdot128_mfma_kernel<N, GATHER, HAS_DENSE, IDS_F32, false>), dim3((unsigned)grid),
+                       dim3(64 * wpb), lds_block, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
+                       append_dense, oob);
   return 0;
 }
 
@@ -200,7 +226,7 @@ bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, i
                                      append_dense, oob, st);                                      \
     else if (has_dense)                                                                           \
       launch_mfma<N_, true, true, 0>(ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,   \
-                                     append_dense, oob, st);                                      \
+                                     append_dense | (getenv("REC_DBG") ? atoi(getenv("REC_DBG")) << 8 : 0), oob, st);                                      \
     else if (ids_f32)                                                                             \
       launch_mfma<N_, true, false, 1>(ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,  \
                                       0, oob, st);                                                \

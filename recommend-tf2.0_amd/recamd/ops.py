@@ -110,7 +110,7 @@ def pairwise_dot(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     B, n, D = x.shape
     P = n * (n - 1) // 2
     if out is None:
-        out = torch.empty((B, P), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, (P + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :P]
     else:
         _rows2d(_chk(out, "out"), "out")
     C.pairwise_dot_f32(x.data_ptr(), B, n, D, out.data_ptr(), out.stride(0), _stream())
@@ -138,7 +138,9 @@ def gather_pairwise_dot(group: TableGroup, ids: torch.Tensor, dense: Optional[to
             raise ValueError(f"dense: expected {(B, D)}, got {tuple(dense.shape)}")
     width = P + (D if (dense is not None and append_dense) else 0)
     if out is None:
-        out = torch.empty((B, width), dtype=torch.float32, device=ids.device)
+        # row stride padded to a multiple of 4 floats: the kernel then stages each sample's results in
+        # LDS and writes aligned 16-B vectors (the pad column holds zeros); consumers take the stride
+        out = torch.empty((B, (width + 3) // 4 * 4), dtype=torch.float32, device=ids.device)[:, :width]
     else:
         _rows2d(_chk(out, "out"), "out")
         if out.shape[0] != B or out.shape[1] < width:

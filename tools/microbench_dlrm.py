@@ -24,7 +24,7 @@ ids = torch.randint(0, a.V, (a.B, a.F), device=dev, dtype=torch.int32, generator
 dense = torch.rand((a.B, a.D), device=dev)
 n = a.F + 1
 P = n * (n - 1) // 2
-out = torch.empty((a.B, P + a.D), dtype=torch.float32, device=dev)
+out = torch.empty((a.B, (P + a.D + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P + a.D]
 
 
 def timeit(fn, name, byts):
@@ -46,9 +46,15 @@ def timeit(fn, name, byts):
 fused_bytes = a.B * (a.F * a.D * 4 + a.F * 4 + a.D * 4 + (P + a.D) * 4)
 timeit(lambda: ops.gather_pairwise_dot(g, ids, dense, out=out), "fused gather+dot", fused_bytes)
 X = torch.cat([ops.gather_concat(g, ids).view(a.B, a.F, a.D), dense[:, None, :]], dim=1).contiguous()
-out2 = torch.empty((a.B, P), dtype=torch.float32, device=dev)
+out2 = torch.empty((a.B, (P + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P]
 timeit(lambda: ops.pairwise_dot(X, out=out2), "plain pairwise_dot", a.B * (n * a.D * 4 + P * 4))
 ref = torch.bmm(X[:4096], X[:4096].transpose(1, 2))
 li, lj = zip(*[(i, j) for i in range(n) for j in range(i)])
 refz = ref[:, list(li), list(lj)]
 print("max abs err vs torch.bmm (first 4096):", float((refz - out[:4096, :P]).abs().max()))
+# A/B in one process: staged (16-B aligned row stride) vs direct (tight 479-float rows) output path
+out_tight = torch.empty((a.B, P + a.D), dtype=torch.float32, device=dev)
+for rep in range(2):
+    timeit(lambda: ops.gather_pairwise_dot(g, ids, dense, out=out), "fused, staged stores (stride 480)", fused_bytes)
+    timeit(lambda: ops.gather_pairwise_dot(g, ids, dense, out=out_tight), "fused, direct stores (stride 479)", fused_bytes)
+print("staged == direct:", bool(torch.equal(out, out_tight)))
