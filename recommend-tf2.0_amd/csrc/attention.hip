@@ -3,6 +3,8 @@
 //   K6  rec_mha_ctr_f32        ctr MultiHeadAttention (AutoInt)   src/ctr/layers/modules.py:285-325
 //   K7  rec_din_attn_pool_f32  DIN AttentionLayer pooling         src/ctr/layers/modules.py:144-175
 //   K8  rec_mha_rowmask_f32    match scaled-dot-product attention src/match/layers/modules.py:76-96,115-131
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rec {
@@ -234,6 +236,9 @@ __global__ __launch_bounds__(256) void mha_rowmask_kernel(const float* __restric
   for (int c = 0; c < DK / 4; ++c) reinterpret_cast<f32x4*>(orow)[c] = acc[c] * inv;
 }
 
+bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
+                               int Sq, int Sk, int dk, int H, float* out, hipStream_t st);
+
 }  // namespace rec
 
 using namespace rec;
@@ -305,6 +310,13 @@ extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* 
   const size_t lds = (size_t)2 * Sk * dk * sizeof(float);
   REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: Sk=%d dk=%d needs %zu B of LDS", who, Sk, dk, lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    const char* e = getenv("REC_MHA_IMPL");  // "valu" forces the round-1 VALU kernel (A/B only)
+    if (!(e && e[0] == 'v') && mha_rowmask_mfma_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, st)) {
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
+  }
   dim3 grid((unsigned)((Sq + 255) / 256), (unsigned)H, (unsigned)B);
 #define REC_MHA(DK_)                                                                               \
   case DK_: {                                                                                      \
@@ -323,3 +335,264 @@ extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* 
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }
+
+// ================================================================================================
+// K8 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32): flash-style, one workgroup of
+// 4 waves per (sample, head); the head's K (row stride DK+4: conflict-free ds_read_b128) and V
+// live in LDS; every wave owns 32-query tiles.
+//
+// Orientation (cdna guide §3 "accumulator tile as the next MFMA's operand"): the scores are
+// computed TRANSPOSED, S^T = K Q^T, so a lane owns ONE query (column) and holds 16 of the 32 keys
+// of a tile in its accumulator registers (the other 16 sit in lane ^ 32): the row softmax is
+// register-local plus one cross-half exchange, and the probabilities are — with no data movement
+// — the B operand of O^T = V^T P^T, whose accumulator again has the query on the lane, so the
+// online-softmax rescale is a per-lane multiply.  k-index permutations are free as long as both
+// operands agree: lane half h holds k in [h*DK/2, (h+1)*DK/2) for Q and K, and key
+// (r&3) + 8(r>>2) + 4h of the tile for P and V.
+// ================================================================================================
+namespace rec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DK>
+__global__ __launch_bounds__(256) void mha_rowmask_mfma_kernel(const float* __restrict__ q,
+                                                               const float* __restrict__ k,
+                                                               const float* __restrict__ v,
+                                                               const float* __restrict__ mask, int Sq,
+                                                               int Sk, int H, float* __restrict__ out) {
+  constexpr int KH = DK / 2;        // k values per lane half = QK^T MFMA steps
+  constexpr int LDK = DK + 4;       // K row stride in LDS (floats)
+  constexpr int NDT = DK / 32;      // 32-wide output column tiles
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int SkP = (Sk + 31) & ~31;
+  float* Ks = lds;                          // [SkP][LDK]
+  float* Vs = lds + (size_t)SkP * LDK;      // [SkP][DK]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int dm = H * DK;
+  const float* kb = k + b * (int64_t)Sk * dm + h * DK;
+  const float* vb = v + b * (int64_t)Sk * dm + h * DK;
+  // stage K and V (pad rows: zeros, so that 0 * V stays 0)
+  for (int e = tid; e < SkP * (DK / 4); e += 256) {
+    const int j = e / (DK / 4), c = e - j * (DK / 4);
+    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
+    if (j < Sk) {
+      kk = reinterpret_cast<const f32x4*>(kb + (int64_t)j * dm)[c];
+      vv = reinterpret_cast<const f32x4*>(vb + (int64_t)j * dm)[c];
+    }
+    *reinterpret_cast<f32x4*>(Ks + (size_t)j * LDK + c * 4) = kk;
+    *reinterpret_cast<f32x4*>(Vs + (size_t)j * DK + c * 4) = vv;
+  }
+  __syncthreads();
+
+  const int ql = lane & 31;   // query within the tile (and key row / d column for operand reads)
+  const int hf = lane >> 5;   // lane half
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)DK);
+  const int nqt = (Sq + 31) >> 5;
+  for (int qt = wv; qt < nqt; qt += 4) {
+    const int qi = qt * 32 + ql;
+    const int qc = qi < Sq ? qi : Sq - 1;
+    // Q operand: B[k][j = query]; lane holds Q[query][hf*KH + s], s = 0..KH-1
+    float qreg[KH];
+    {
+      const f32x4* qp = reinterpret_cast<const f32x4*>(q + (b * Sq + qc) * (int64_t)dm + h * DK + hf * KH);
+#pragma unroll
+      for (int c = 0; c < KH / 4; ++c) {
+        const f32x4 t = qp[c];
+        qreg[4 * c] = t.x;
+        qreg[4 * c + 1] = t.y;
+        qreg[4 * c + 2] = t.z;
+        qreg[4 * c + 3] = t.w;
+      }
+    }
+    const bool masked = mask[b * Sq + qc] == 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[NDT];
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+
+    for (int kt = 0; kt < SkP; kt += 32) {
+      // ---- S^T tile = K_tile (32 keys x DK) . Q_tile^T
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const float* krow = Ks + (size_t)(kt + ql) * LDK + hf * KH;
+#pragma unroll
+      for (int c = 0; c < KH / 4; ++c) {
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(krow + 4 * c);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * c + 1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * c + 2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * c + 3], s, 0, 0, 0);
+      }
+      // ---- online softmax for this lane's query over its 16 keys (+ the other half's 16)
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        float x = masked ? 0.f : s[r] * scale_log2e;   // masked query row: every logit equal
+        x = key < Sk ? x : -INFINITY;                   // LDS pad rows
+        s[r] = x;
+        tmax = fmaxf(tmax, x);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      const float resc = exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(s[r] - m_new);
+        s[r] = p;
+        psum += p;
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * resc + psum;
+      m_run = m_new;
+      // ---- O^T += V_tile^T . P^T : A[i = d][k = key], B[k = key][j = query] = s[r]
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= resc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          const float a = Vs[(size_t)key * DK + t * 32 + ql];
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], o[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- write O: lane = query, register r of tile t = column t*32 + (r&3) + 8(r>>2) + 4hf
+    if (qi < Sq) {
+      const float inv = 1.f / l_run;
+      float* orow = out + (b * Sq + qi) * (int64_t)dm + h * DK;
+#pragma unroll
+      for (int t = 0; t < NDT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 w = {o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv};
+          *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g + 4 * hf) = w;
+        }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K8, few query rows (Sq <= 8: SASRec's last encoder block only encodes x[:, -1],
+// src/match/sasrec/model.py:88): "decode-style", HBM-bound — K and V of the head are read exactly
+// once, straight from global memory.  One wave per (sample, head, query); LPK = DK/4 lanes share a
+// key (16 B each), 64/LPK keys per wave step, one online-softmax state per lane group, merged at
+// the end by a butterfly over the group index.
+// ------------------------------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __restrict__ q,
+                                                                 const float* __restrict__ k,
+                                                                 const float* __restrict__ v,
+                                                                 const float* __restrict__ mask, int Sq,
+                                                                 int Sk, int H, int64_t total,
+                                                                 float* __restrict__ out) {
+  constexpr int LPK = DK / 4;       // lanes per key
+  constexpr int KPS = 64 / LPK;     // keys per wave step
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, i, h) flattened
+  if (w >= total) return;
+  const int h = (int)(w % H);
+  const int64_t bi = w / H;         // b * Sq + i
+  const int64_t b = bi / Sq;
+  const int dm = H * DK;
+  const int sub = lane % LPK, grp = lane / LPK;
+  const f32x4 qv = reinterpret_cast<const f32x4*>(q + bi * dm + h * DK)[sub];
+  const bool masked = mask[bi] == 0.f;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)DK);
+  const float* kb = k + b * (int64_t)Sk * dm + h * DK + sub * 4;
+  const float* vb = v + b * (int64_t)Sk * dm + h * DK + sub * 4;
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;
+  for (int j0 = 0; j0 < Sk; j0 += KPS * U) {
+    f32x4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = j0 + u * KPS + grp;
+      j = j < Sk ? j : Sk - 1;
+      kr[u] = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * dm);
+      vr[u] = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * dm);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * KPS + grp;
+      const f32x4 pr = kr[u] * qv;
+      float s = pr.x + pr.y + pr.z + pr.w;
+#pragma unroll
+      for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = masked ? 0.f : s * scale_log2e;     // masked query row: all logits equal -> uniform
+      if (j >= Sk) s = -INFINITY;
+      const float mn = fmaxf(m, s);
+      const float sc = mn == -INFINITY ? 0.f : exp2f(m - mn);
+      const float p = mn == -INFINITY ? 0.f : exp2f(s - mn);
+      acc = acc * sc + vr[u] * p;
+      l = l * sc + p;
+      m = mn;
+    }
+  }
+  // merge the KPS group states (butterfly over lane bits >= log2(LPK))
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64);
+    const float l2 = __shfl_xor(l, o, 64);
+    f32x4 a2;
+    a2.x = __shfl_xor(acc.x, o, 64);
+    a2.y = __shfl_xor(acc.y, o, 64);
+    a2.z = __shfl_xor(acc.z, o, 64);
+    a2.w = __shfl_xor(acc.w, o, 64);
+    const float mn = fmaxf(m, m2);
+    const float s1 = m == -INFINITY ? 0.f : exp2f(m - mn);
+    const float s2 = m2 == -INFINITY ? 0.f : exp2f(m2 - mn);
+    acc = acc * s1 + a2 * s2;
+    l = l * s1 + l2 * s2;
+    m = mn;
+  }
+  if (grp == 0) reinterpret_cast<f32x4*>(out + bi * dm + h * DK)[sub] = acc * (1.f / l);
+}
+
+template <int DK>
+static bool launch_mha_mfma(const float* q, const float* k, const float* v, const float* mask, int64_t B,
+                            int Sq, int Sk, int H, float* out, hipStream_t st) {
+  const int SkP = (Sk + 31) & ~31;
+  const size_t lds = (size_t)SkP * (2 * DK + 4) * sizeof(float);
+  if (lds > 160 * 1024) return false;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mha_rowmask_mfma_kernel<DK>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return false;
+  }
+  hipLaunchKernelGGL((mha_rowmask_mfma_kernel<DK>), dim3((unsigned)H, (unsigned)B), dim3(256), lds, st, q, k, v,
+                     mask, Sq, Sk, H, out);
+  return true;
+}
+
+bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
+                               int Sq, int Sk, int dk, int H, float* out, hipStream_t st) {
+  if (Sq <= 8 && (dk == 64 || dk == 32 || dk == 16)) {  // few query rows: HBM-bound decode-style kernel
+    const int64_t total = B * Sq * H;
+    const dim3 grid((unsigned)((total + 3) / 4)), block(256);
+    if (dk == 64)
+      hipLaunchKernelGGL((mha_rowmask_smallq_kernel<64>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out);
+    else if (dk == 32)
+      hipLaunchKernelGGL((mha_rowmask_smallq_kernel<32>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out);
+    else
+      hipLaunchKernelGGL((mha_rowmask_smallq_kernel<16>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out);
+    return true;
+  }
+  if (Sq < 16 || B > 65535) return false;
+  if (dk == 64) return launch_mha_mfma<64>(q, k, v, mask, B, Sq, Sk, H, out, st);
+  if (dk == 32) return launch_mha_mfma<32>(q, k, v, mask, B, Sq, Sk, H, out, st);
+  return false;
+}
+
+}  // namespace rec

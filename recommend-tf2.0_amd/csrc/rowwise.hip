@@ -350,6 +350,14 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
   if (i < total) out[i] = x[i] * sc[i / d];
 }
 
+// d % 4 == 0 and 16-B aligned pointers: one float4 per thread
+__global__ __launch_bounds__(256) void scale_rows_vec_kernel(const f32x4* __restrict__ x,
+                                                             const float* __restrict__ sc, int64_t total4,
+                                                             int d4, f32x4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total4) out[i] = x[i] * sc[i / d4];
+}
+
 __global__ __launch_bounds__(256) void dice_kernel(const float* __restrict__ x,
                                                    const float* __restrict__ alpha,
                                                    const float* __restrict__ mean,
@@ -386,8 +394,15 @@ extern "C" int rec_scale_rows_f32(const float* x, const float* row_scale, int64_
   if (rows == 0) return REC_OK;
   REC_CHECK_ARG(x && row_scale && out, REC_EINVAL, "%s: NULL pointer", who);
   const int64_t total = rows * d;
-  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, row_scale, total, d, out);
+  if (d % 4 == 0 && aligned16(x) && aligned16(out)) {
+    const int64_t total4 = total / 4;
+    hipLaunchKernelGGL(scale_rows_vec_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(x), row_scale,
+                       total4, d / 4, reinterpret_cast<f32x4*>(out));
+  } else {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, row_scale, total, d, out);
+  }
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }
