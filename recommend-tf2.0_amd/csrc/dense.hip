@@ -6,6 +6,8 @@
 // (src/match/layers/modules.py:146-149) and the attention projections.  Not the headline kernel
 // (SURVEY K11): a plain LDS-tiled 128x128x16 block, 4 waves as 2x2, each wave 2x2 tiles of 32x32.
 // Roofline: fp32 MFMA (157.3 TFLOP/s dense).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rec {
@@ -125,6 +127,96 @@ __global__ __launch_bounds__(256) void dense_narrow_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Skinny Dense (K <= 128, N <= 128): the layers of this zoo are narrow (64x64 attention projections,
+// 64<->128 FFN, 32..256-wide towers) while M is huge (batch x seq), so the op is HBM-bound:
+// W (<= 64 KiB) is staged in LDS once per workgroup, every wave streams 32-row tiles of x straight
+// from global memory into MFMA A operands (lane half h holds k in [h*K/2, (h+1)*K/2): 16-B loads,
+// the k-permutation is matched on the B side) and keeps all N/32 accumulator tiles in registers:
+// x is read once, out written once.
+// ------------------------------------------------------------------------------------------------
+template <int KH /* K/2 */, int NT /* ceil(N/32) */>
+__global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                           const float* __restrict__ W,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ alpha, int act,
+                                                           int64_t M, int K, int N,
+                                                           float* __restrict__ out, int64_t out_stride) {
+  constexpr int LDW = NT * 32;
+  extern __shared__ __attribute__((aligned(16))) float Ws[];  // [K][LDW], zero padded columns
+  const int tid = threadIdx.x;
+  for (int e = tid; e < K * LDW; e += 256) {
+    const int kk = e / LDW, n = e - kk * LDW;
+    Ws[e] = n < N ? W[(int64_t)kk * N + n] : 0.f;
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int rl = lane & 31, hf = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (M + 31) >> 5;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int kh = K >> 1;  // runtime K/2 (<= KH)
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wv; t < ntiles; t += nwaves) {
+    const int64_t row = t * 32 + rl;
+    const int64_t rc = row < M ? row : M - 1;
+    float a[KH];
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + rc * x_stride + hf * kh);
+#pragma unroll
+    for (int c = 0; c < KH / 4; ++c) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (4 * c < kh) v = xp[c];
+      a[4 * c] = v.x;
+      a[4 * c + 1] = v.y;
+      a[4 * c + 2] = v.z;
+      a[4 * c + 3] = v.w;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KH; ++s2) {
+      if (s2 < kh) {
+        const float* wrow = Ws + (size_t)(hf * kh + s2) * LDW + rl;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wrow[j * 32], acc[j], 0, 0, 0);
+      }
+    }
+    const int64_t r0 = t * 32;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 32 + rl;
+      if (col < N) {
+        const float bb = bias ? bias[col] : 0.f;
+        const float al = alpha ? alpha[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t orow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          if (orow < M) out[orow * out_stride + col] = act_apply(acc[j][r] + bb, act, al);
+        }
+      }
+    }
+  }
+}
+
+template <int KH, int NT>
+static void launch_skinny(const float* x, int64_t x_stride, const float* W, const float* bias,
+                          const float* alpha, int act, int64_t M, int K, int N, float* out,
+                          int64_t out_stride, hipStream_t st) {
+  const size_t lds = (size_t)K * NT * 32 * sizeof(float);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(dense_skinny_kernel<KH, NT>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int64_t ntiles = (M + 31) / 32;
+  int64_t blocks = (ntiles + 3) / 4;
+  if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: W is staged once per workgroup
+  hipLaunchKernelGGL((dense_skinny_kernel<KH, NT>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_stride, W,
+                     bias, alpha, act, M, K, N, out, out_stride);
+}
+
 }  // namespace rec
 
 using namespace rec;
@@ -140,6 +232,21 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
   if (M == 0) return REC_OK;
   REC_CHECK_ARG(x && W && out, REC_EINVAL, "%s: NULL pointer", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool skinny = N > 8 && N <= 128 && K >= 8 && K <= 128 && K % 8 == 0 && M >= 256 && aligned16(x) &&
+                      x_stride % 4 == 0 && !(getenv("REC_DENSE_IMPL") && getenv("REC_DENSE_IMPL")[0] == 't');
+  if (skinny) {
+    const int nt = (N + 31) / 32;
+#define REC_SK(KH_, NT_)                                                                        \
+  if (K / 2 <= KH_ && nt == NT_) {                                                              \
+    launch_skinny<KH_, NT_>(x, x_stride, W, bias, alpha, act, M, K, N, out, out_stride, st);    \
+    REC_CHECK_LAUNCH(who);                                                                      \
+    return REC_OK;                                                                              \
+  }
+    REC_SK(16, 1) REC_SK(16, 2) REC_SK(16, 3) REC_SK(16, 4)
+    REC_SK(32, 1) REC_SK(32, 2) REC_SK(32, 3) REC_SK(32, 4)
+    REC_SK(64, 1) REC_SK(64, 2) REC_SK(64, 3) REC_SK(64, 4)
+#undef REC_SK
+  }
   if (N <= 8) {
     hipLaunchKernelGGL((dense_narrow_kernel<8>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x,
                        x_stride, W, bias, alpha, act, M, K, N, out, out_stride);
