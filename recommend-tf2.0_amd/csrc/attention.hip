@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256) void mha_rowmask_kernel(const float* __restric
 
 bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
                                int Sq, int Sk, int dk, int H, float* out, hipStream_t st);
+bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
+                           const float* Wq, const float* Wk, const float* Wv, const float* W0, int H, int S,
+                           int act, float* out, hipStream_t st);
 
 }  // namespace rec
 
@@ -252,6 +255,14 @@ extern "C" int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv
   REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_TANH, REC_EINVAL, "%s: bad act %d", who, act);
   if (B == 0) return REC_OK;
   REC_CHECK_ARG(xq && xk && xv && Wq && Wk && Wv && out, REC_EINVAL, "%s: NULL pointer", who);
+  {
+    const char* e = getenv("REC_MHA_IMPL");  // "valu" forces the LDS/VALU kernel (A/B only)
+    if (!(e && e[0] == 'v') && mha_ctr_mfma_dispatch(xq, xk, xv, B, N, din, Wq, Wk, Wv, W0, H, S, act, out,
+                                                     reinterpret_cast<hipStream_t>(stream))) {
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
+  }
   const int nx = (xq == xk && xk == xv) ? 1 : 3;
   size_t regionA = (size_t)nx * N * din;
   if ((size_t)H * N * N > regionA) regionA = (size_t)H * N * N;
@@ -593,6 +604,175 @@ bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, c
   if (dk == 64) return launch_mha_mfma<64>(q, k, v, mask, B, Sq, Sk, H, out, st);
   if (dk == 32) return launch_mha_mfma<32>(q, k, v, mask, B, Sq, Sk, H, out, st);
   return false;
+}
+
+}  // namespace rec
+
+// ================================================================================================
+// K6 on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): AutoInt interacting layer with head size
+// S = 16 (BASELINE config 3: 39 fields, d = 16, H = 2).  One WAVE per sample (4 per workgroup), all
+// intermediates in a wave-private LDS region, no barriers after the weights are staged.
+//   Q, K, V = act(X W)            16x16 output tiles, written to LDS
+//   S^T     = K_h Q_h^T * sqrt(S) transposed scores: a lane owns one query, its 4 lane groups hold
+//                                  the keys -> softmax = 12 local values + two cross-group shuffles
+//   O^T     = V_h^T P^T            P^T accumulators are the B operand as they stand
+//   R^T     = W0^T Xv^T            residual branch computed transposed so that it lands in the
+//                                  same (query on lane, column in register) layout as O^T
+//   out     = relu(O + act(R))    16-B stores
+// ================================================================================================
+namespace rec {
+
+__global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restrict__ xq,
+                                                           const float* __restrict__ xk,
+                                                           const float* __restrict__ xv, int64_t B, int N,
+                                                           int din, const float* __restrict__ Wq,
+                                                           const float* __restrict__ Wk,
+                                                           const float* __restrict__ Wv,
+                                                           const float* __restrict__ W0, int H, int act,
+                                                           int nx, float* __restrict__ out) {
+  constexpr int S = 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HS = H * S;
+  const int NP = (N + 15) & ~15;   // padded field count
+  const int NT = NP >> 4;
+  const int LDX = din + 1;         // X row stride (bank spread for the row-per-lane operand reads)
+  const int LDQ = HS + 1;
+  // block-shared weights [4][din][HS]
+  float* Wsh = lds;
+  const int wsz = din * HS;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < wsz; e += 256) {
+    Wsh[e] = Wq[e];
+    Wsh[wsz + e] = Wk[e];
+    Wsh[2 * wsz + e] = Wv[e];
+    Wsh[3 * wsz + e] = W0 ? W0[e] : 0.f;
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = (int64_t)blockIdx.x * 4 + wv;
+  if (b >= B) return;  // wave-uniform; no barrier below
+  const int per_wave = nx * NP * LDX + 3 * NP * LDQ;
+  float* Xs = lds + 4 * wsz + (size_t)wv * per_wave;   // [nx][NP][LDX]
+  float* Qs = Xs + nx * NP * LDX;                       // [NP][LDQ]
+  float* Ks = Qs + NP * LDQ;
+  float* Vs = Ks + NP * LDQ;
+  const float* xin[3] = {xq, xk, xv};
+  for (int c = 0; c < nx; ++c)
+    for (int e = lane; e < NP * din; e += 64) {
+      const int n = e / din, kk = e - n * din;
+      Xs[(c * NP + n) * LDX + kk] = n < N ? xin[c][(b * N + n) * (int64_t)din + kk] : 0.f;
+    }
+  const float* Xq = Xs;
+  const float* Xk = nx == 3 ? Xs + NP * LDX : Xs;
+  const float* Xv = nx == 3 ? Xs + 2 * NP * LDX : Xs;
+  const int lr = lane & 15, g = lane >> 4;
+  const int ksteps = din >> 2;
+
+  // ---- projections Q, K, V -> LDS
+  for (int m = 0; m < 3; ++m) {
+    const float* X = m == 0 ? Xq : (m == 1 ? Xk : Xv);
+    const float* Wm = Wsh + m * wsz;
+    float* dst = m == 0 ? Qs : (m == 1 ? Ks : Vs);
+    for (int rt = 0; rt < NT; ++rt)
+      for (int ct = 0; ct < H; ++ct) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < ksteps; ++st) {
+          const float a = X[(rt * 16 + lr) * LDX + 4 * st + g];
+          const float bw = Wm[(4 * st + g) * HS + ct * 16 + lr];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dst[(rt * 16 + 4 * g + r) * LDQ + ct * 16 + lr] = act_apply(acc[r], act, 0.f);
+      }
+  }
+  // wave-private LDS: the wave's own ds ops are ordered, no barrier needed
+
+  const float scale = 4.0f * 1.4426950408889634f;  // "/ (S ** -0.5)" = x sqrt(16), folded with log2(e)
+  for (int h = 0; h < H; ++h)
+    for (int qt = 0; qt < NT; ++qt) {
+      // ---- transposed scores for this query tile against every key tile (NT <= 4)
+      f32x4 sc[4];
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        sc[kt] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (kt < NT) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            const float a = Ks[(kt * 16 + lr) * LDQ + h * 16 + 4 * st + g];
+            const float bq = Qs[(qt * 16 + lr) * LDQ + h * 16 + 4 * st + g];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            const float x = key < N ? acc[r] * scale : -INFINITY;
+            sc[kt][r] = x;
+            mloc = fmaxf(mloc, x);
+          }
+        }
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      float lsum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(sc[kt][r] - mloc);   // pad keys: exp2(-inf) = 0
+          sc[kt][r] = p;
+          lsum += p;
+        }
+      lsum += __shfl_xor(lsum, 16, 64);
+      lsum += __shfl_xor(lsum, 32, 64);
+      const float inv = 1.f / lsum;
+      // ---- O^T = V_h^T P^T
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = Vs[(kt * 16 + 4 * g + r) * LDQ + h * 16 + lr];
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sc[kt][r] * inv, o, 0, 0, 0);
+          }
+        }
+      // ---- residual, transposed: R^T[c][n] = sum_k W0[k][c] Xv[n][k]
+      if (W0) {
+        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+        const float* W0s = Wsh + 3 * wsz;
+        for (int st = 0; st < ksteps; ++st) {
+          const float a = W0s[(4 * st + g) * HS + h * 16 + lr];
+          const float bx = Xv[(qt * 16 + lr) * LDX + 4 * st + g];
+          rr = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx, rr, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r] + act_apply(rr[r], act, 0.f), 0.f);
+      }
+      const int qi = qt * 16 + lr;
+      if (qi < N) *reinterpret_cast<f32x4*>(out + (b * N + qi) * (int64_t)HS + h * 16 + 4 * g) = o;
+    }
+}
+
+bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
+                           const float* Wq, const float* Wk, const float* Wv, const float* W0, int H, int S,
+                           int act, float* out, hipStream_t st) {
+  if (S != 16 || N > 64 || din % 4 != 0 || din > 256 || !aligned16(out)) return false;
+  const int nx = (xq == xk && xk == xv) ? 1 : 3;
+  const int HS = H * 16, NP = (N + 15) & ~15;
+  const size_t floats = (size_t)4 * din * HS + (size_t)4 * ((size_t)nx * NP * (din + 1) + (size_t)3 * NP * (HS + 1));
+  const size_t lds = floats * sizeof(float);
+  if (lds > 160 * 1024) return false;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(mha_ctr_mfma_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return false;
+  hipLaunchKernelGGL(mha_ctr_mfma_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, st, xq, xk, xv, B, N, din,
+                     Wq, Wk, Wv, W0, H, act, nx, out);
+  return true;
 }
 
 }  // namespace rec

@@ -39,6 +39,19 @@ def test_mha_ctr_distinct_qkv(dev):
     assert close(out, ref.mha_ctr(xq, xk, xv, Ws[0], Ws[1], Ws[2], Ws[3], H, S, "relu"))
 
 
+@pytest.mark.parametrize("B,N,din,H", [(9, 11, 8, 2), (130, 39, 16, 2), (5, 64, 64, 4), (3, 16, 4, 1), (6, 50, 20, 3)])
+@pytest.mark.parametrize("use_res", [False, True])
+def test_mha_ctr_mfma_shapes_distinct_qkv(dev, B, N, din, H, use_res):
+    """S = 16 runs on the fp32 matrix cores; list-of-3 input form, odd field counts, several heads."""
+    from recamd import ops
+    rng = np.random.default_rng(B + N + din)
+    xq, xk, xv = [(rng.normal(size=(B, N, din)) * 0.5).astype(np.float32) for _ in range(3)]
+    Ws = [(rng.normal(size=(din, H * 16)) / np.sqrt(din)).astype(np.float32) for _ in range(4)]
+    out = ops.mha_ctr(T(xq, dev), T(xk, dev), T(xv, dev), T(Ws[0], dev), T(Ws[1], dev), T(Ws[2], dev),
+                      T(Ws[3], dev) if use_res else None, H, 16, "relu").cpu().numpy()
+    assert close(out, ref.mha_ctr(xq, xk, xv, Ws[0], Ws[1], Ws[2], Ws[3] if use_res else None, H, 16, "relu"))
+
+
 def test_mha_ctr_kat_uniform_and_scale(dev):
     """Wq = Wk = 0 => uniform attention => out = mean_n act(X Wv); scale is x sqrt(S) (S=16 -> x4):
     with q=k=one-hot rows the logits are exactly 4 on the diagonal."""
