@@ -153,6 +153,17 @@ int rec_din_attn_pool_f32(const float* q, const float* k, const float* v, const 
                           const float* W, const float* bias, const float* alpha, int32_t act,
                           int64_t B, int32_t T, int32_t d, float* out, void* stream);
 
+/* Fused history gather + DIN pooling: k = v = concat_t(tables[t][ids[b, j, t]]) is never materialised
+ * (the (B,T,d) history of src/ctr/din/model.py:71-74 costs as much HBM traffic as the pooling itself).
+ * tables: n_tab descriptors sharing one dim Dt (d = n_tab * Dt <= 256); ids: (B, T, n_tab) int32 or
+ * fp32 (truncated); mask as above, or mask == NULL with mask_from_ids != 0: slot j is real iff
+ * ids[b, j, 0] != 0 (pad id 0). */
+int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc* tables, int32_t n_tab,
+                                 const void* ids, int32_t ids_dtype, const float* mask,
+                                 int32_t mask_from_ids, const float* W, const float* bias,
+                                 const float* alpha, int32_t act, int64_t B, int32_t T, float* out,
+                                 int32_t* oob_flag, void* stream);
+
 /* ---- a12 / K8: match MultiHeadAttention (row-masked, non-causal, no out-proj) ---------------
  * src/match/layers/modules.py:115-131 with scaled_dot_product_attention :76-96.
  * q: (B, Sq, dm), k/v: (B, Sk, dm) already-projected tensors (projection = rec_dense_f32 with

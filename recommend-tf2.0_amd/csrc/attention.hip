@@ -167,6 +167,85 @@ __global__ __launch_bounds__(256) void din_pool_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// K7 fused with the history gather (K1): same online-softmax pooling, but the T history rows are
+// fetched straight from the embedding tables (n_tab tables x Dt columns, lane -> (table, 16-B
+// chunk)); the (B, T, d) tensor never exists.  HBM: T*d*4 B of rows + T*n_tab*4 B of ids per sample.
+// ------------------------------------------------------------------------------------------------
+struct DinTables {
+  const float* base[8];
+  int32_t vocab[8];
+};
+
+template <int IDS_F32>
+__global__ __launch_bounds__(256) void din_gather_pool_kernel(const float* __restrict__ q, DinTables tb,
+                                                              int n_tab, int Dt, const void* __restrict__ ids,
+                                                              const float* __restrict__ mask, int mask_mode,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ alpha, int act,
+                                                              int64_t B, int T, float* __restrict__ out,
+                                                              int* __restrict__ oob) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int d = n_tab * Dt;
+  const int nv = d >> 2;
+  const bool on = lane < nv;
+  const int lpt = Dt >> 2;                    // lanes per table
+  const int tab = on ? lane / lpt : 0;
+  const int col = on ? (lane - tab * lpt) * 4 : 0;
+  const float* tbase = tb.base[tab];
+  const uint32_t tvocab = (uint32_t)tb.vocab[tab];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 qv = on ? reinterpret_cast<const f32x4*>(q + b * d)[lane] : z4;
+  const f32x4 w1 = on ? reinterpret_cast<const f32x4*>(W)[lane] : z4;
+  const f32x4 w2 = on ? reinterpret_cast<const f32x4*>(W + d)[lane] : z4;
+  const f32x4 w3 = on ? reinterpret_cast<const f32x4*>(W + 2 * d)[lane] : z4;
+  const f32x4 w4 = on ? reinterpret_cast<const f32x4*>(W + 3 * d)[lane] : z4;
+  const f32x4 u = w2 - w3 + qv * w4;
+  const f32x4 cw = qv * (w1 + w3);
+  const float c0 = wave_sum(cw.x + cw.y + cw.z + cw.w) + bias[0];
+  const float al = alpha ? alpha[0] : 0.f;
+  const int64_t idbase = b * (int64_t)T * n_tab;
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = z4;
+  constexpr int U = 4;
+  for (int t0 = 0; t0 < T; t0 += U) {
+    f32x4 kr[U];
+    int32_t id0[U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const int t = t0 + e < T ? t0 + e : T - 1;
+      const int32_t id = load_id<IDS_F32>(ids, idbase + (int64_t)t * n_tab + tab);
+      id0[e] = load_id<IDS_F32>(ids, idbase + (int64_t)t * n_tab);
+      const bool ok = (uint32_t)id < tvocab;
+      if (!ok && on && oob) *oob = 1;
+      const f32x4 row = *reinterpret_cast<const f32x4*>(tbase + (int64_t)(ok ? id : 0) * Dt + col);
+      kr[e] = (on && ok) ? row : z4;
+    }
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      if (t0 + e >= T) break;
+      const f32x4 pr = kr[e] * u;
+      float s = wave_sum(pr.x + pr.y + pr.z + pr.w) + c0;
+      s = act_apply(s, act, al);
+      bool pad;
+      if (mask_mode == 0) pad = true;                                   // non-tensor mask: all padded
+      else if (mask_mode == 1) pad = mask[b * T + t0 + e] == 0.f;
+      else pad = id0[e] == 0;                                           // slot real iff first id != 0
+      if (pad) s = kNegPad;
+      const float mn = fmaxf(m, s);
+      const float sc = expf(m - mn);
+      const float p = expf(s - mn);
+      acc = acc * sc + kr[e] * p;
+      l = l * sc + p;
+      m = mn;
+    }
+  }
+  if (on) reinterpret_cast<f32x4*>(out + b * d)[lane] = acc * (1.f / l);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8 — match attention.  One workgroup per (sample, head, 256-query tile); the head's K and V
 // (Sk x dk each) are staged in LDS once per workgroup and read by broadcast (every thread reads
 // the same K_j / V_j address: conflict-free), one query row per thread, online softmax.
@@ -300,6 +379,43 @@ extern "C" int rec_din_attn_pool_f32(const float* q, const float* k, const float
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(din_pool_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, q, k, v, mask, W,
                      bias, alpha, act, mask ? 1 : 0, B, T, d, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc* tables, int32_t n_tab,
+                                            const void* ids, int32_t ids_dtype, const float* mask,
+                                            int32_t mask_from_ids, const float* W, const float* bias,
+                                            const float* alpha, int32_t act, int64_t B, int32_t T,
+                                            float* out, int32_t* oob_flag, void* stream) {
+  const char* who = "rec_gather_din_attn_pool_f32";
+  REC_CHECK_ARG(tables && n_tab >= 1 && n_tab <= 8, REC_ESHAPE, "%s: n_tab=%d outside [1,8]", who, n_tab);
+  const int Dt = tables[0].dim;
+  DinTables tb;
+  for (int t = 0; t < 8; ++t) {
+    const rec_table_desc& s = tables[t < n_tab ? t : 0];
+    REC_CHECK_ARG(s.base && aligned16(s.base) && s.dim == Dt && s.vocab >= 1 && s.vocab <= 0x7fffffffLL,
+                  REC_ESHAPE, "%s: tables must be 16-B aligned and share one dim", who);
+    tb.base[t] = s.base;
+    tb.vocab[t] = (int32_t)s.vocab;
+  }
+  const int d = n_tab * Dt;
+  REC_CHECK_ARG(B >= 0 && T >= 1 && Dt % 4 == 0 && d <= 256, REC_ESHAPE, "%s: need Dt %% 4 == 0 and d <= 256", who);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_PRELU && (act != REC_ACT_PRELU || alpha), REC_EINVAL,
+                "%s: bad act", who);
+  REC_CHECK_ARG(ids_dtype == REC_IDS_I32 || ids_dtype == REC_IDS_F32, REC_EINVAL, "%s: bad ids_dtype", who);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(q && ids && W && bias && out && aligned16(q) && aligned16(W) && aligned16(out), REC_EINVAL,
+                "%s: NULL or unaligned pointer", who);
+  const int mode = mask ? 1 : (mask_from_ids ? 2 : 0);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+  if (ids_dtype == REC_IDS_F32)
+    hipLaunchKernelGGL((din_gather_pool_kernel<1>), grid, block, 0, st, q, tb, n_tab, Dt, ids, mask, mode, W, bias,
+                       alpha, act, B, T, out, oob_flag);
+  else
+    hipLaunchKernelGGL((din_gather_pool_kernel<0>), grid, block, 0, st, q, tb, n_tab, Dt, ids, mask, mode, W, bias,
+                       alpha, act, B, T, out, oob_flag);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }

@@ -135,6 +135,20 @@ PYBIND11_MODULE(_C, m) {
           "rec_din_attn_pool_f32");
   });
 
+  m.def("gather_din_attn_pool_f32",
+        [](ptr_t q, const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, ptr_t mask,
+           int mask_from_ids, ptr_t W, ptr_t bias, ptr_t alpha, int act, int64_t B, int T, ptr_t out,
+           ptr_t oob, ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_din_attn_pool_f32(P<const float>(q), d.data(), (int32_t)d.size(),
+                                             P<const void>(ids), ids_dtype, P<const float>(mask),
+                                             mask_from_ids, P<const float>(W), P<const float>(bias),
+                                             P<const float>(alpha), act, B, T, P<float>(out),
+                                             P<int32_t>(oob), P<void>(stream)),
+                "rec_gather_din_attn_pool_f32");
+        });
+
   m.def("mha_rowmask_f32", [](ptr_t q, ptr_t k, ptr_t v, ptr_t mask, int64_t B, int Sq, int Sk,
                               int dm, int H, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;

@@ -21,11 +21,12 @@ from recamd.nn import Model, to_device_f32
 class DIN(Model):
     def __init__(self, sparse_feature_dict, sparse_feature_index, att_hidden_units=64,
                  ffn_hidden_units=(80, 40), att_activation='prelu', ffn_activation='prelu', maxlen=10,
-                 dnn_dropout=0., att_l2_reg=1e-4, embed_reg=1e-4, mode='intended'):
+                 dnn_dropout=0., att_l2_reg=1e-4, embed_reg=1e-4, mode='intended', fuse_history=True):
         super().__init__()
         if mode not in ('intended', 'as_written'):
             raise ValueError("mode must be 'intended' or 'as_written'")
         self.mode = mode
+        self.fuse_history = fuse_history
         self.maxlen = maxlen
         self.sparse_feature_dict = sparse_feature_dict
         self.user_sparse_feature_index, self.item_sparse_feature_index, self.behavior_feature_index = \
@@ -84,6 +85,16 @@ class DIN(Model):
         item_embed = torch.cat([item_sparse_input, item_embeddings], dim=-1)           # :66-68 (ids as floats)
         d_item = item_embeddings.shape[1]
         beh_ids = self._cols(behavior_input, self._beh_cols)
+        if self.mode == 'intended' and self._beh_regular and self.fuse_history:
+            # fused history gather + pooling: the (B, maxlen, d) behaviour tensor is never materialised
+            n_item = len(self._item_group)
+            L = self.attention_layer
+            if not L.built:
+                L.build(d_item)
+            att_outputs = ops.gather_din_attention_pool(
+                item_embeddings, self._item_group, beh_ids.contiguous().view(B, self.maxlen, n_item), None,
+                L._w['kernel'], L._w['bias'], L.activation, L._w.get('alpha'), mask_from_ids=True)
+            return self._head(user_embed, item_embed, att_outputs)
         if self._beh_regular:
             n_item = len(self._item_group)
             behavior_embed = ops.gather_concat(self._item_group, beh_ids.view(B * self.maxlen, n_item))
@@ -101,6 +112,9 @@ class DIN(Model):
             n_item = len(self._item_group)
             mask = (beh_ids.view(B, self.maxlen, n_item)[:, :, 0] != 0).to(torch.float32)
             att_outputs = self.attention_layer([item_embeddings, behavior_embed, behavior_embed, mask])
+        return self._head(user_embed, item_embed, att_outputs)
+
+    def _head(self, user_embed, item_embed, att_outputs):
         all_inputs = torch.cat([user_embed, item_embed, att_outputs], dim=-1)          # :81
         x = all_inputs
         for i, dense in enumerate(self.ffn):                                           # :83-87 (BN folded)

@@ -399,3 +399,26 @@ def dice(x: torch.Tensor, alpha: torch.Tensor, mean=None, var=None, eps: float =
     C.dice_f32(x.data_ptr(), _chk(alpha, "alpha").data_ptr(), _ptr(mean), _ptr(var), float(eps), x.numel() // d, d,
                out.data_ptr(), _stream())
     return out
+
+
+def gather_din_attention_pool(q, group: TableGroup, ids, mask, W, bias, act="sigmoid", alpha=None,
+                              mask_from_ids=False, oob_flag=None) -> torch.Tensor:
+    """Fused history gather + DIN pooling: ids (B, T, n_tab) index `group`'s tables (one shared dim);
+    k = v = the gathered (B, T, n_tab*Dt) history, never materialised.  mask: (B,T) float tensor, or
+    None with mask_from_ids=True (slot real iff ids[b,t,0] != 0), or None (uniform, modules.py:164-165)."""
+    _chk(q, "q")
+    _chk(ids, "ids", None)
+    if ids.dim() != 3 or not ids.is_contiguous() or ids.shape[2] != len(group):
+        raise ValueError("ids: expected contiguous (B, T, n_tab)")
+    B, T, n_tab = ids.shape
+    d = sum(group.dims)
+    if len(set(group.dims)) != 1 or q.shape != (B, d) or not q.is_contiguous():
+        raise ValueError("gather_din_attention_pool: tables must share one dim and q must be contiguous (B, n_tab*Dt)")
+    if mask is not None:
+        mask = _chk(mask, "mask").contiguous()
+    W = _chk(W, "W").reshape(-1)
+    out = torch.empty((B, d), dtype=torch.float32, device=q.device)
+    C.gather_din_attn_pool_f32(q.data_ptr(), group.descs, ids.data_ptr(), _ids_dtype(ids), _ptr(mask),
+                               1 if mask_from_ids else 0, W.data_ptr(), _chk(bias, "bias").data_ptr(), _ptr(alpha),
+                               _act_id(act), B, T, out.data_ptr(), _ptr(oob_flag), _stream())
+    return out

@@ -142,3 +142,36 @@ def test_mha_rowmask(dev, B, Sq, Sk, dm, H):
         for b in range(B):
             for i in np.nonzero(padded[b])[0]:
                 assert close(out[b, i], mean_v[b])
+
+
+@pytest.mark.parametrize("B,T_,n_tab,Dt", [(33, 100, 3, 64), (7, 10, 1, 16), (20, 37, 4, 32), (5, 3, 2, 128)])
+@pytest.mark.parametrize("mask_mode", ["ids", "tensor", "none"])
+def test_gather_din_attention_pool_fused(dev, B, T_, n_tab, Dt, mask_mode):
+    """Fused history gather + pooling == oracle gather followed by the oracle AttentionLayer."""
+    from recamd import ops
+    rng = np.random.default_rng(B + T_ + Dt)
+    V = 50
+    d = n_tab * Dt
+    tables = [rng.normal(size=(V, Dt)).astype(np.float32) for _ in range(n_tab)]
+    lens = rng.integers(0, T_ + 1, size=B)
+    ids = rng.integers(1, V, size=(B, T_, n_tab)).astype(np.int32)
+    ids[np.arange(T_)[None, :] < (T_ - lens)[:, None]] = 0
+    if B > 10:
+        ids[1, T_ - 1, n_tab - 1] = V + 3  # OOB id in a real slot -> zero sub-row
+    q = rng.normal(size=(B, d)).astype(np.float32)
+    W = (rng.normal(size=(4 * d, 1)) / np.sqrt(d)).astype(np.float32)
+    b = rng.normal(size=1).astype(np.float32)
+    g = ops.TableGroup([T(t, dev) for t in tables])
+    hist = np.concatenate([ref.embedding_lookup(tables[t].astype(np.float64), ids[:, :, t]) for t in range(n_tab)], axis=-1)
+    if mask_mode == "ids":
+        mask_np, mask_t, mfi = (ids[:, :, 0] != 0).astype(np.float64), None, True
+    elif mask_mode == "tensor":
+        mask_np = (rng.random((B, T_)) > 0.5).astype(np.float32)
+        mask_t, mfi = T(mask_np, dev), False
+    else:
+        mask_np, mask_t, mfi = None, None, False
+    flag = ops.new_oob_flag(dev)
+    out = ops.gather_din_attention_pool(T(q, dev), g, T(ids, dev), mask_t, T(W, dev), T(b, dev), "sigmoid",
+                                        mask_from_ids=mfi, oob_flag=flag).cpu().numpy()
+    assert close(out, ref.din_attention_layer(q, hist, hist, mask_np, W, b, "sigmoid"))
+    assert int(flag.item()) == (1 if B > 10 else 0)

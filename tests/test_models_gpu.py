@@ -208,6 +208,9 @@ def test_din_intended(dev, ffn_act):
                          f64(w[f'ffn_{i}/dice/bn/moving_variance']))
     exp = ref.sigmoid(ref.dense(x, f64(w['final_output/kernel']), f64(w['final_output/bias'])))
     assert close(out, exp)
+    # the unfused path (materialised history + AttentionLayer) gives the same result
+    m.fuse_history = False
+    assert close(m([ud, us, idn, its, beh]).cpu().numpy(), exp)
 
 
 def test_din_as_written(dev):

@@ -69,11 +69,16 @@ def config4():
     g_ms = timeit(lambda: ops.gather_concat(g, ids.view(B * T, 3), out=hist))
     hv = hist.view(B, T, d)
     p_ms = timeit(lambda: ops.din_attention_pool(q, hv, hv, mask, W, b, 'sigmoid'))
+    f_ms = timeit(lambda: ops.gather_din_attention_pool(q, g, ids, None, W, b, 'sigmoid', mask_from_ids=True))
+    fused_bytes = B * (T * d * 4 + T * 3 * 4 + 2 * d * 4)
     gather_bytes = B * T * 3 * (2 * 64 * 4 + 4)
     pool_bytes = B * (T * d * 4 + T * 4 + 2 * d * 4)
     return {"config": "DIN pooling T=100 d=192 B=8192", "history_gather_ms": round(g_ms, 4),
             "history_gather_GBs": round(gather_bytes / g_ms / 1e6, 1), "pool_ms": round(p_ms, 4),
             "pool_GBs": round(pool_bytes / p_ms / 1e6, 1), "bound": "hbm", "peak_GBs": HBM_PEAK,
+            "fused_gather_pool_ms": round(f_ms, 4), "fused_GBs": round(fused_bytes / f_ms / 1e6, 1),
+            "fused_frac": round(fused_bytes / f_ms / 1e6 / HBM_PEAK, 4),
+            "fused_samples_per_s": round(B / f_ms * 1e3, 1),
             "pool_frac": round(pool_bytes / p_ms / 1e6 / HBM_PEAK, 4),
             "gather_frac": round(gather_bytes / g_ms / 1e6 / HBM_PEAK, 4)}
 
