@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void din_gather_pool_kernel(const float* __res
   const int64_t idbase = b * (int64_t)T * n_tab;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = z4;
-  constexpr int U = 4;
+  constexpr int U = 4;  // 8 measured slower (0.197 vs 0.146 ms at config 4)
   for (int t0 = 0; t0 < T; t0 += U) {
     f32x4 kr[U];
     int32_t id0[U];
