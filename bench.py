@@ -99,7 +99,7 @@ def main():
 
     # ---- synthetic data, generated on device (there is no dataset; BASELINE config 2) ----------
     gen = torch.Generator(device=dev).manual_seed(0)
-    if a.placement == "replicated" or world == 1:
+    if a.placement == "replicated":
         arena = torch.empty((F, V, D), dtype=torch.float32, device=dev)
         arena.uniform_(-0.05, 0.05, generator=gen)  # keras 'random_uniform' (dlrm/model.py:34)
         group = ops.TableGroup([arena[f] for f in range(F)])

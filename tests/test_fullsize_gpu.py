@@ -1,0 +1,86 @@
+"""BASELINE full-size checks (configs[1]: 65 536 x 26 x 1M x 128) through size-independent properties,
+plus oracle checks on sampled rows (the fp64 oracle cannot afford the whole batch in seconds).
+
+  gather      : bit-exact vs an independent device gather (torch indexing) on the WHOLE output;
+                checksum-of-checksums; sampled rows vs the numpy oracle.
+  fused dot   : sampled samples vs the fp64 oracle; bilinearity (scaling the dense vector scales exactly
+                its 26 dots by the same power of two); symmetry of the source (permuting two fields
+                permutes dots); dense pass-through bit-exact; idempotence (two launches agree bit-for-bit).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as ref
+from tests.util import close
+
+pytestmark = pytest.mark.gpu
+
+B, F, V, D = 65536, 26, 1_000_000, 128
+
+
+@pytest.fixture(scope="module")
+def world(dev):
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20 * 2 ** 30:
+        pytest.skip("needs ~16 GB of HBM")
+    from recamd import ops
+    gen = torch.Generator(device=dev).manual_seed(0)
+    arena = torch.empty((F, V, D), dtype=torch.float32, device=dev).uniform_(-0.05, 0.05, generator=gen)
+    ids = torch.randint(0, V, (B, F), device=dev, dtype=torch.int32, generator=gen)
+    dense = torch.rand((B, D), device=dev, generator=gen)
+    g = ops.TableGroup([arena[f] for f in range(F)])
+    yield arena, ids, dense, g
+    del arena
+
+
+def test_full_gather_bit_exact_and_checksums(world, dev):
+    from recamd import ops
+    arena, ids, dense, g = world
+    out = ops.gather_concat(g, ids)
+    fidx = torch.arange(F, device=dev)[None, :].expand(B, F)
+    exp = arena[fidx.reshape(-1), ids.long().reshape(-1)].view(B, F * D)   # independent device gather
+    assert torch.equal(out.view(torch.int32), exp.view(torch.int32))
+    # checksum of checksums over int32 views (order-independent, exact)
+    a = out.view(torch.int32).to(torch.int64).sum(dim=1)
+    b = exp.view(torch.int32).to(torch.int64).sum(dim=1)
+    assert int(a.sum()) == int(b.sum()) and torch.equal(a, b)
+    # sampled rows vs the numpy oracle
+    rows = np.random.default_rng(1).integers(0, B, size=64)
+    ids_h = ids[rows].cpu().numpy()
+    tabs_h = [arena[f][torch.from_numpy(ids_h[:, f]).long().to(dev)].cpu().numpy() for f in range(F)]
+    for r, row in enumerate(rows):
+        want = np.concatenate([tabs_h[f][r] for f in range(F)])
+        assert np.array_equal(out[row].cpu().numpy(), want)
+
+
+def test_full_fused_dot_properties(world, dev):
+    from recamd import ops
+    arena, ids, dense, g = world
+    P = 27 * 26 // 2
+    out = ops.gather_pairwise_dot(g, ids, dense)
+    out2 = ops.gather_pairwise_dot(g, ids, dense)
+    assert torch.equal(out, out2)                                   # idempotent / deterministic
+    assert torch.equal(out[:, P:], dense)                           # pass-through bit-exact
+    # sampled samples vs the fp64 oracle
+    rows = np.random.default_rng(2).integers(0, B, size=48)
+    ids_h = ids[rows].cpu().numpy()
+    emb = np.stack([arena[f][torch.from_numpy(ids_h[:, f]).long().to(dev)].cpu().numpy() for f in range(F)], axis=1)
+    X = np.concatenate([emb, dense[rows].cpu().numpy()[:, None, :]], axis=1)
+    assert close(out[rows][:, :P].cpu().numpy(), ref.pairwise_dot(X))
+    # bilinearity: dense * 2 (exact in fp32) doubles exactly the dots (26, j) and leaves the rest
+    out_s = ops.gather_pairwise_dot(g, ids, dense * 2.0)
+    last = 26 * 25 // 2
+    assert torch.equal(out_s[:, :last], out[:, :last])
+    assert torch.equal(out_s[:, last:P], out[:, last:P] * 2.0)
+    # swapping fields 0 and 1 (tables and id columns) leaves dot (1,0) unchanged and swaps (i,0) <-> (i,1)
+    g_sw = ops.TableGroup([arena[1], arena[0]] + [arena[f] for f in range(2, F)])
+    ids_sw = ids.clone()
+    ids_sw[:, 0], ids_sw[:, 1] = ids[:, 1], ids[:, 0]
+    out_sw = ops.gather_pairwise_dot(g_sw, ids_sw, dense)
+    assert close(out_sw[:, 0].cpu().numpy(), out[:, 0].cpu().numpy())
+    i = 5
+    assert close(out_sw[:, i * (i - 1) // 2 + 0].cpu().numpy(), out[:, i * (i - 1) // 2 + 1].cpu().numpy())
+    # fused == materialised gather followed by the plain kernel (same per-lane arithmetic)
+    Xd = torch.cat([ops.gather_concat(g, ids[:4096]).view(4096, F, D), dense[:4096, None, :]], dim=1).contiguous()
+    assert torch.equal(ops.pairwise_dot(Xd), out[:4096, :P])
