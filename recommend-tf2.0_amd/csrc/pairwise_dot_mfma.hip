@@ -131,11 +131,6 @@ __global__ __launch_bounds__(256, PREFETCH ? 2 : 3) void pairdot128_mfma_kernel(
 
     // ---- Z tiles: z00 = X0 X0^T, z10 = X1 X0^T, z11 = X1 X1^T
     f32x4 z00 = {0.f, 0.f, 0.f, 0.f}, z10 = z00, z11 = z00;
-    const int dbg = append_dense >> 8;
-    if (dbg & 1) {  // ablation: no MFMA
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { z00 += xa[0][c]; if constexpr (NT == 2) z11 += xa[1][c]; }
-    } else
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
 #pragma unroll
@@ -156,7 +151,6 @@ __global__ __launch_bounds__(256, PREFETCH ? 2 : 3) void pairdot128_mfma_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i0 = 4 * g + e;
-      if (dbg & 2) { if (z00[e] == 1234.5f) orow[0] = z00[e] + z10[e] + z11[e]; continue; }
       if (i0 < N && j0 < i0) orow[i0 * (i0 - 1) / 2 + j0] = z00[e];
       if constexpr (NT == 2) {
         const int i1 = 16 + i0;
@@ -168,7 +162,7 @@ __global__ __launch_bounds__(256, PREFETCH ? 2 : 3) void pairdot128_mfma_kernel(
       }
     }
     if constexpr (HAS_DENSE) {
-      if ((append_dense & 0xff) && half == ((N - 1) & 1)) {
+      if (append_dense && half == ((N - 1) & 1)) {
         float* od = orow + P + sl * 4;  // only 4-B aligned in general (P odd)
         od[0] = __uint_as_float(dense_regs.x);
         od[1] = __uint_as_float(dense_regs.y);
@@ -226,7 +220,7 @@ bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, i
                                      append_dense, oob, st);                                      \
     else if (has_dense)                                                                           \
       launch_mfma<N_, true, true, 0>(ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,   \
-                                     append_dense | (getenv("REC_DBG") ? atoi(getenv("REC_DBG")) << 8 : 0), oob, st);                                      \
+                                     append_dense, oob, st);                                      \
     else if (ids_f32)                                                                             \
       launch_mfma<N_, true, false, 1>(ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,  \
                                       0, oob, st);                                                \
