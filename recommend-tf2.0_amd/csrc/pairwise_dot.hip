@@ -394,7 +394,7 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   TableSet ts;
   int rc = fill_table_set(tables, F, &ts, who);
   if (rc != REC_OK) return rc;
-  REC_CHECK_ARG(ids && out, REC_EINVAL, "%s: NULL ids/out", who);
+  REC_CHECK_ARG(B == 0 || (ids && out), REC_EINVAL, "%s: NULL ids/out", who);
   REC_CHECK_ARG(ids_dtype == REC_IDS_I32 || ids_dtype == REC_IDS_F32, REC_EINVAL,
                 "%s: bad ids_dtype %d", who, ids_dtype);
   REC_CHECK_ARG(B >= 0 && ids_stride >= F, REC_ESHAPE, "%s: B=%lld ids_stride=%lld F=%d", who,

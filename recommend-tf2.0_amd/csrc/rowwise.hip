@@ -429,10 +429,10 @@ extern "C" int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_
                                 const float* second, int64_t second_stride, int32_t M, int64_t B,
                                 float* out, float* workspace, void* stream) {
   const char* who = "rec_fm_layer_f32";
-  REC_CHECK_ARG(first && w && second && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
   REC_CHECK_ARG(B >= 0 && L1 >= 1 && M >= 1 && first_stride >= L1 && second_stride >= M, REC_ESHAPE,
                 "%s: bad shape B=%lld L1=%d M=%d", who, (long long)B, L1, M);
   if (B == 0) return REC_OK;
+  REC_CHECK_ARG(first && w && second && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // rows per wave chosen so that the number of block partials stays <= kFmMaxPartials
   int64_t rpw = (B + (int64_t)4 * kFmMaxPartials - 1) / ((int64_t)4 * kFmMaxPartials);
@@ -452,10 +452,10 @@ extern "C" int rec_cross_f32(const float* x, int64_t x_stride, int32_t dim, cons
                              const float* b, int32_t L, int64_t B, float* out, int64_t out_stride,
                              void* stream) {
   const char* who = "rec_cross_f32";
-  REC_CHECK_ARG(x && out && (L == 0 || (w && b)), REC_EINVAL, "%s: NULL pointer", who);
   REC_CHECK_ARG(B >= 0 && dim >= 1 && L >= 0 && x_stride >= dim && out_stride >= dim, REC_ESHAPE,
                 "%s: bad shape B=%lld dim=%d L=%d", who, (long long)B, dim, L);
   if (B == 0) return REC_OK;
+  REC_CHECK_ARG(x && out && (L == 0 || (w && b)), REC_EINVAL, "%s: NULL pointer", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
   const bool vec = dim % 4 == 0 && aligned16(x) && aligned16(out) && aligned16(w) && aligned16(b) &&
