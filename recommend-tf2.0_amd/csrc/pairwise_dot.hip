@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256, REC_PAIRDOT_MIN_WAVES) void pairdot_kernel(
   constexpr int P = N * (N - 1) / 2;
   constexpr int F = GATHER ? (HAS_DENSE ? N - 1 : N) : 0;
 
+  const int ids_f32 = IDS_F32 | (append_dense >> 16);  // runtime ids dtype (bit 16), keeps the
+  append_dense &= 0xffff;                               // instantiation count (and build time) down
   const int lane = threadIdx.x & 63;
   const int sl = lane % LPR;          // lane within the sample
   const int sw = lane / LPR;          // sample within the wave
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, REC_PAIRDOT_MIN_WAVES) void pairdot_kernel(
       const int f = f0 + sl;
       uint64_t src = reinterpret_cast<uint64_t>(ts.base[0]) | 1u;  // bit 0: row reads as zeros
       if (f < F) {
-        const int32_t id = load_id<IDS_F32>(ids, b * ids_stride + f);
+        const int32_t id = ids_f32 ? load_id<1>(ids, b * ids_stride + f) : load_id<0>(ids, b * ids_stride + f);
         if ((uint32_t)id < (uint32_t)ts.vocab[f]) {
           src = reinterpret_cast<uint64_t>(ts.base[f] + (int64_t)id * D);
         } else if (oob) {
@@ -316,7 +318,7 @@ static void launch_pairdot(const TableSet& ts, const void* ids, int64_t ids_stri
   constexpr int SPW = 64 / LPR;
   const int64_t waves = (B + SPW - 1) / SPW;
   const int64_t blocks = (waves + 3) / 4;
-  const int W = N * (N - 1) / 2 + (append_dense ? LPR * 4 : 0);
+  const int W = N * (N - 1) / 2 + ((append_dense & 0xffff) ? LPR * 4 : 0);
   const bool staged = aligned16(out) && out_stride % 4 == 0 && out_stride >= (W + 3) / 4 * 4;
   if (staged)
     hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, true>), dim3((unsigned)blocks),
@@ -334,7 +336,7 @@ static void launch_pairdot(const TableSet& ts, const void* ids, int64_t ids_stri
 // the small ones serve tests and narrower models; everything else takes the generic kernel
 // (plain) or is rejected (fused).
 #define REC_PAIRDOT_SHAPES(X) \
-  X(32, 27) X(32, 26) X(32, 9) X(32, 4) X(16, 27) X(16, 9) X(16, 4) X(8, 9) X(4, 27) X(4, 5)
+  X(32, 27) X(32, 26) X(32, 9) X(32, 4) X(16, 27) X(16, 9) X(8, 9) X(4, 27) X(4, 5)
 
 extern "C" int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_t D, float* out,
                                     int64_t out_stride, void* stream) {
@@ -430,21 +432,13 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
 #define REC_TRY(LPR_, N_)                                                                          \
   if (D == (LPR_)*4 && n == (N_)) {                                                                \
-    if (dense) {                                                                                   \
-      if (ids_dtype == REC_IDS_F32)                                                                \
-        launch_pairdot<LPR_, N_, true, true, 1>(ts, ids, ids_stride, dense, dense_stride, B, out,  \
-                                                out_stride, append_dense, oob_flag, st);           \
-      else                                                                                         \
-        launch_pairdot<LPR_, N_, true, true, 0>(ts, ids, ids_stride, dense, dense_stride, B, out,  \
-                                                out_stride, append_dense, oob_flag, st);           \
-    } else {                                                                                       \
-      if (ids_dtype == REC_IDS_F32)                                                                \
-        launch_pairdot<LPR_, N_, true, false, 1>(ts, ids, ids_stride, nullptr, 0, B, out,          \
-                                                 out_stride, 0, oob_flag, st);                     \
-      else                                                                                         \
-        launch_pairdot<LPR_, N_, true, false, 0>(ts, ids, ids_stride, nullptr, 0, B, out,          \
-                                                 out_stride, 0, oob_flag, st);                     \
-    }                                                                                              \
+    const int flags = (ids_dtype == REC_IDS_F32) ? (1 << 16) : 0;                                  \
+    if (dense)                                                                                     \
+      launch_pairdot<LPR_, N_, true, true, 0>(ts, ids, ids_stride, dense, dense_stride, B, out,    \
+                                              out_stride, append_dense | flags, oob_flag, st);     \
+    else                                                                                           \
+      launch_pairdot<LPR_, N_, true, false, 0>(ts, ids, ids_stride, nullptr, 0, B, out,            \
+                                               out_stride, flags, oob_flag, st);                   \
     REC_CHECK_LAUNCH(who);                                                                         \
     return REC_OK;                                                                                 \
   }
