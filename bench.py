@@ -85,11 +85,19 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal knobs (one-GPU boxes only): REC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # REC_BENCH_BACKEND=gloo replaces RCCL, to exercise the multi-rank control flow without N GPUs
+    if os.environ.get("REC_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("REC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from recamd import ops
 
