@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
                                                            int64_t M, int K, int N,
                                                            float* __restrict__ out, int64_t out_stride) {
   constexpr int LDW = NT * 32;
+  constexpr int LDO = NT * 32 + 4;  // output staging row stride (16-B aligned rows, bank spread)
   extern __shared__ __attribute__((aligned(16))) float Ws[];  // [K][LDW], zero padded columns
+  float* Ot = Ws + (size_t)K * LDW;                           // [4 waves][32][LDO]
+  const bool staged = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) && (out_stride % 4 == 0);
   const int tid = threadIdx.x;
   for (int e = tid; e < K * LDW; e += 256) {
     const int kk = e / LDW, n = e - kk * LDW;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ntiles = (M + 31) >> 5;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int kh = K >> 1;  // runtime K/2 (<= KH)
+  constexpr int kh = KH;  // K == 2*KH exactly (dispatch): no runtime guards inside the MFMA loop
   for (int64_t t = (int64_t)blockIdx.x * 4 + wv; t < ntiles; t += nwaves) {
     const int64_t row = t * 32 + rl;
     const int64_t rc = row < M ? row : M - 1;
@@ -164,8 +167,7 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
     const f32x4* xp = reinterpret_cast<const f32x4*>(x + rc * x_stride + hf * kh);
 #pragma unroll
     for (int c = 0; c < KH / 4; ++c) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (4 * c < kh) v = xp[c];
+      const f32x4 v = xp[c];
       a[4 * c] = v.x;
       a[4 * c + 1] = v.y;
       a[4 * c + 2] = v.z;
@@ -178,24 +180,44 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < KH; ++s2) {
-      if (s2 < kh) {
-        const float* wrow = Ws + (size_t)(hf * kh + s2) * LDW + rl;
+      const float* wrow = Ws + (size_t)(hf * kh + s2) * LDW + rl;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wrow[j * 32], acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wrow[j * 32], acc[j], 0, 0, 0);
     }
     const int64_t r0 = t * 32;
+    if (staged) {
+      // 4-B-per-lane stores are the slow path on this part (see pairwise_dot.hip): stage the 32 x N tile in
+      // a wave-private LDS region and write 16 B per lane, whole rows at a time
+      float* ot = Ot + wv * (32 * LDO);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = j * 32 + rl;
-      if (col < N) {
-        const float bb = bias ? bias[col] : 0.f;
-        const float al = alpha ? alpha[col] : 0.f;
+      for (int j = 0; j < NT; ++j) {
+        const int col = j * 32 + rl;
+        const float bb = (bias && col < N) ? bias[col] : 0.f;
+        const float al = (alpha && col < N) ? alpha[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t orow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-          if (orow < M) out[orow * out_stride + col] = act_apply(acc[j][r] + bb, act, al);
+        for (int r = 0; r < 16; ++r)
+          ot[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDO + col] = act_apply(acc[j][r] + bb, act, al);
+      }
+      const int n4 = N >> 2;
+      for (int v = lane; v < 32 * n4; v += 64) {
+        const int rr = v / n4, c4 = v - rr * n4;
+        if (r0 + rr < M)
+          *reinterpret_cast<f32x4*>(out + (r0 + rr) * out_stride + c4 * 4) =
+              *reinterpret_cast<const f32x4*>(ot + rr * LDO + c4 * 4);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = j * 32 + rl;
+        if (col < N) {
+          const float bb = bias ? bias[col] : 0.f;
+          const float al = alpha ? alpha[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t orow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (orow < M) out[orow * out_stride + col] = act_apply(acc[j][r] + bb, act, al);
+          }
         }
       }
     }
@@ -206,9 +228,9 @@ template <int KH, int NT>
 static void launch_skinny(const float* x, int64_t x_stride, const float* W, const float* bias,
                           const float* alpha, int act, int64_t M, int K, int N, float* out,
                           int64_t out_stride, hipStream_t st) {
-  const size_t lds = (size_t)K * NT * 32 * sizeof(float);
+  const size_t lds = ((size_t)K * NT * 32 + (size_t)4 * 32 * (NT * 32 + 4)) * sizeof(float);
   if (lds > 64 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(dense_skinny_kernel<KH, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_skinny_kernel<KH, NT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int64_t ntiles = (M + 31) / 32;
   int64_t blocks = (ntiles + 3) / 4;
@@ -232,16 +254,17 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
   if (M == 0) return REC_OK;
   REC_CHECK_ARG(x && W && out, REC_EINVAL, "%s: NULL pointer", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool skinny = N > 8 && N <= 128 && K >= 8 && K <= 128 && K % 8 == 0 && M >= 256 && aligned16(x) &&
+  const bool skinny = N > 8 && N <= 64 && (K == 16 || K == 32 || K == 64 || K == 128) && M >= 256 && aligned16(x) &&
                       x_stride % 4 == 0 && !(getenv("REC_DENSE_IMPL") && getenv("REC_DENSE_IMPL")[0] == 't');
   if (skinny) {
     const int nt = (N + 31) / 32;
 #define REC_SK(KH_, NT_)                                                                        \
-  if (K / 2 <= KH_ && nt == NT_) {                                                              \
+  if (K / 2 == KH_ && nt == NT_) {                                                              \
     launch_skinny<KH_, NT_>(x, x_stride, W, bias, alpha, act, M, K, N, out, out_stride, st);    \
     REC_CHECK_LAUNCH(who);                                                                      \
     return REC_OK;                                                                              \
   }
+    REC_SK(8, 1) REC_SK(8, 2) REC_SK(8, 3) REC_SK(8, 4)
     REC_SK(16, 1) REC_SK(16, 2) REC_SK(16, 3) REC_SK(16, 4)
     REC_SK(32, 1) REC_SK(32, 2) REC_SK(32, 3) REC_SK(32, 4)
     REC_SK(64, 1) REC_SK(64, 2) REC_SK(64, 3) REC_SK(64, 4)
