@@ -73,10 +73,14 @@ class ShardedTables:
         dev = local_tables[0].device
         # one arena (F, rows_local, D): virtual local row = f * rows_local + local
         first = local_tables[0]
+        need = self.F * self.rows_local * self.D * 4
+        st0 = first.untyped_storage()
         contiguous_arena = all(
             t.shape[0] == self.rows_local and t.is_contiguous() and
+            t.untyped_storage().data_ptr() == st0.data_ptr() and      # views of ONE allocation ...
             t.data_ptr() == first.data_ptr() + f * self.rows_local * self.D * 4
-            for f, t in enumerate(local_tables))
+            for f, t in enumerate(local_tables)) and \
+            (first.data_ptr() - st0.data_ptr()) + need <= st0.nbytes()  # ... that really holds F shards
         if contiguous_arena:
             self.arena = torch.as_strided(first, (self.F * self.rows_local, self.D), (self.D, 1))
         else:
