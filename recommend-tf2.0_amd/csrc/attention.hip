@@ -482,7 +482,7 @@ namespace rec {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int DK>
-__global__ __launch_bounds__(256) void mha_rowmask_mfma_kernel(const float* __restrict__ q,
+__global__ __launch_bounds__(512) void mha_rowmask_mfma_kernel(const float* __restrict__ q,
                                                                const float* __restrict__ k,
                                                                const float* __restrict__ v,
                                                                const float* __restrict__ mask, int Sq,
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void mha_rowmask_mfma_kernel(const float* __re
   const float* kb = k + b * (int64_t)Sk * dm + h * DK;
   const float* vb = v + b * (int64_t)Sk * dm + h * DK;
   // stage K and V (pad rows: zeros, so that 0 * V stays 0)
-  for (int e = tid; e < SkP * (DK / 4); e += 256) {
+  for (int e = tid; e < SkP * (DK / 4); e += blockDim.x) {
     const int j = e / (DK / 4), c = e - j * (DK / 4);
     f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
     if (j < Sk) {
@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256) void mha_rowmask_mfma_kernel(const float* __re
   const int hf = lane >> 5;   // lane half
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)DK);
   const int nqt = (Sq + 31) >> 5;
-  for (int qt = wv; qt < nqt; qt += 4) {
+  // 8 waves = 2 per SIMD: one wave's softmax (VALU) hides under its partner's MFMAs
+  const int nwv = blockDim.x >> 6;
+  for (int qt = wv; qt < nqt; qt += nwv) {
     const int qi = qt * 32 + ql;
     const int qc = qi < Sq ? qi : Sq - 1;
     // Q operand: B[k][j = query]; lane holds Q[query][hf*KH + s], s = 0..KH-1
@@ -698,7 +700,9 @@ static bool launch_mha_mfma(const float* q, const float* k, const float* v, cons
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return false;
   }
-  hipLaunchKernelGGL((mha_rowmask_mfma_kernel<DK>), dim3((unsigned)H, (unsigned)B), dim3(256), lds, st, q, k, v,
+  const int nqt = (Sq + 31) / 32;
+  const int threads = nqt > 4 ? 512 : 256;
+  hipLaunchKernelGGL((mha_rowmask_mfma_kernel<DK>), dim3((unsigned)H, (unsigned)B), dim3(threads), lds, st, q, k, v,
                      mask, Sq, Sk, H, out);
   return true;
 }

@@ -294,15 +294,6 @@ bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, i
                               int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
                               int append_dense, int* oob, hipStream_t st);
 
-bool pairdot128_w64_dispatch(const TableSet& ts, bool gather, bool has_dense, int ids_f32, int n,
-                             const void* ids, int64_t ids_stride, const float* xin,
-                             int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
-                             int append_dense, int* oob, hipStream_t st);
-static bool use_w64() {
-  const char* e = getenv("REC_PAIRDOT_IMPL");
-  return e && e[0] == 'w';
-}
-
 // REC_PAIRDOT_IMPL=mfma selects the matrix-core variant for D = 128 (pairwise_dot_mfma.hip); it is
 // parity-green but currently latency-bound (247 us vs 231 us at 65 536 x 27 x 128, round 1), so
 // the register-tiled VALU kernel below stays the default.  A/B measurements only.
@@ -320,13 +311,15 @@ static void launch_pairdot(const TableSet& ts, const void* ids, int64_t ids_stri
   const int64_t blocks = (waves + 3) / 4;
   const int W = N * (N - 1) / 2 + ((append_dense & 0xffff) ? LPR * 4 : 0);
   const bool staged = aligned16(out) && out_stride % 4 == 0 && out_stride >= (W + 3) / 4 * 4;
+  constexpr int tpb = 256;  // 64 / 128 / 256 threads per workgroup measured equal (212 / 206 / 210 us)
+  const int64_t nblk = blocks;
   if (staged)
-    hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, true>), dim3((unsigned)blocks),
-                       dim3(256), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
+    hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, true>), dim3((unsigned)nblk),
+                       dim3(tpb), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
                        append_dense, oob);
   else
-    hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, false>), dim3((unsigned)blocks),
-                       dim3(256), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
+    hipLaunchKernelGGL((pairdot_kernel<LPR, N, GATHER, HAS_DENSE, IDS_F32, false>), dim3((unsigned)nblk),
+                       dim3(tpb), 0, st, ts, ids, ids_stride, xin, xin_stride, B, out, out_stride,
                        append_dense, oob);
 }
 
@@ -351,12 +344,6 @@ extern "C" int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TableSet ts{};
   const bool vec_ok = D % 4 == 0 && aligned16(x);
-  if (vec_ok && D == 128 && use_w64() &&
-      pairdot128_w64_dispatch(ts, false, false, 0, n, nullptr, 0, x, (int64_t)n * D, B, out, out_stride,
-                              0, nullptr, st)) {
-    REC_CHECK_LAUNCH(who);
-    return REC_OK;
-  }
   if (vec_ok && D == 128 && use_mfma() &&
       pairdot128_mfma_dispatch(ts, false, false, 0, n, nullptr, 0, x, (int64_t)n * D, B, out,
                                out_stride, 0, nullptr, st)) {
@@ -417,12 +404,6 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (D == 128 && use_w64() &&
-      pairdot128_w64_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids, ids_stride,
-                              dense, dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
-    REC_CHECK_LAUNCH(who);
-    return REC_OK;
-  }
   if (D == 128 && use_mfma() &&
       pairdot128_mfma_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids,
                                ids_stride, dense, dense_stride, B, out, out_stride, append_dense,
