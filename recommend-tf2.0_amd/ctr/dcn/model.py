@@ -28,7 +28,19 @@ class DCN(Model):
     def call(self, inputs, **kwargs):
         sparse_inputs = to_device_ids(inputs, self.device)
         x = ops.gather_concat(self._group, sparse_inputs)                  # dcn/model.py:47
-        cross_x = self.cross_network(x)                                    # :51
-        dnn_x = self.dnn_network(x)                                        # :53
-        total_x = torch.cat([cross_x, dnn_x], dim=-1)                      # :55
+        # tf.concat([cross_x, dnn_x]) (:55) without a copy: both producers write straight into one
+        # (B, dim + H) buffer (16-B aligned column offsets)
+        B, dim = x.shape
+        H = self.dnn_network.dnn_network[-1].units
+        pad = (-dim) % 4
+        total = torch.empty((B, dim + pad + H + ((-H) % 4)), dtype=torch.float32, device=self.device)
+        if not self.cross_network.built:
+            self.cross_network.build(dim)
+        cw = self.cross_network._w
+        ops.cross_network(x, cw['cross_weights'], cw['cross_bias'], out=total[:, :dim])     # :51
+        if pad == 0:
+            self.dnn_network(x, out=total[:, dim:dim + H])                                    # :53
+            total_x = total[:, :dim + H]
+        else:
+            total_x = torch.cat([total[:, :dim], self.dnn_network(x)], dim=-1)
         return ops.add_sigmoid(self.dense_final(total_x))                  # :56

@@ -45,11 +45,21 @@ class DLRM(Model):
         dense_inputs, sparse_inputs = inputs
         dense_inputs = to_device_f32(dense_inputs, self.device)
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
+        B = sparse_inputs.shape[0]
         dense_fea = self.bot_dnn(dense_inputs)                                 # intended :44
         if self.interaction == 'dot':
             x = ops.gather_pairwise_dot(self._group, sparse_inputs, dense_fea, append_dense=True)
         else:
-            sparse_embed = ops.gather_concat(self._group, sparse_inputs)       # :45
-            x = torch.cat([sparse_embed, dense_fea], dim=-1)                   # :48
+            # tf.concat([sparse_embed, dense_fea]) (:48) without a copy: the gather writes the sparse part
+            # of one (B, sum D + bot) buffer, the bottom MLP's last layer wrote its tail
+            W = self._group.width
+            Hb = dense_fea.shape[1]
+            if W % 4 == 0:
+                buf = torch.empty((B, W + Hb + ((-Hb) % 4)), dtype=torch.float32, device=self.device)
+                ops.gather_concat(self._group, sparse_inputs, out=buf)             # :45
+                buf[:, W:W + Hb] = dense_fea
+                x = buf[:, :W + Hb]
+            else:
+                x = torch.cat([ops.gather_concat(self._group, sparse_inputs), dense_fea], dim=-1)
         top = self.final_dense(self.top_dnn(x))                                # intended :50-51
         return ops.add_sigmoid(top)                                            # :53

@@ -182,7 +182,7 @@ def fm_layer(first: torch.Tensor, second: torch.Tensor, w: torch.Tensor) -> torc
     return out
 
 
-def cross_network(x: torch.Tensor, W: torch.Tensor, Bv: torch.Tensor) -> torch.Tensor:
+def cross_network(x: torch.Tensor, W: torch.Tensor, Bv: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """DCN CrossNetwork (src/ctr/layers/modules.py:105-112): x (B,dim); W, Bv (L,dim)."""
     _rows2d(_chk(x, "x"), "x")
     _chk(W, "W")
@@ -191,7 +191,12 @@ def cross_network(x: torch.Tensor, W: torch.Tensor, Bv: torch.Tensor) -> torch.T
     L = W.shape[0]
     if W.shape != (L, dim) or Bv.shape != (L, dim) or not W.is_contiguous() or not Bv.is_contiguous():
         raise ValueError("cross_network: W and Bv must be contiguous (L, dim)")
-    out = torch.empty((B, dim), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, dim), dtype=torch.float32, device=x.device)
+    else:
+        _rows2d(_chk(out, "out"), "out")
+        if out.shape != (B, dim):
+            raise ValueError("cross_network: out must be (B, dim)")
     C.cross_f32(x.data_ptr(), x.stride(0), dim, W.data_ptr(), Bv.data_ptr(), L, B, out.data_ptr(), out.stride(0),
                 _stream())
     return out
