@@ -106,6 +106,17 @@ int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_t L1, const
                      const float* second, int64_t second_stride, int32_t M,
                      int64_t B, float* out, float* workspace, void* stream);
 
+/* Fused K1+K3 (DeepFM, src/ctr/deep_fm/model.py:53-59): gathers the F rows of every sample into the
+ * concat buffer `emb_out` (tables[f].out_col = column of field f; the DNN consumes it) and, in the
+ * same pass over the rows, accumulates the FM layer's three sums, so sparse_embed is not re-read:
+ *   fm_out[b] = sum_batch(dense @ w[:nd] + sparse_embed @ w[nd:]) + 0.5((sum x)^2 - sum x^2)
+ * All tables share one dim D (D/4 a power of two <= 64).  w: (nd + F*D) in concat order
+ * [dense, field 0, field 1, ...].  workspace: rec_fm_layer_workspace_floats(B) floats. */
+int rec_gather_fm_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                      int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
+                      const float* w, int64_t B, float* emb_out, int64_t emb_stride, float* fm_out,
+                      float* workspace, int32_t* oob_flag, void* stream);
+
 /* ---- a4 / K4: DCN CrossNetwork, src/ctr/layers/modules.py:105-112 --------------------------
  * x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,  l = 0..L-1;  x: (B, dim), w,b: (L, dim) */
 int rec_cross_f32(const float* x, int64_t x_stride, int32_t dim, const float* w, const float* b,

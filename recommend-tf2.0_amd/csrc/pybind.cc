@@ -85,6 +85,19 @@ PYBIND11_MODULE(_C, m) {
           "rec_fm_layer_f32");
   });
 
+  m.def("gather_fm_f32",
+        [](const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, int64_t ids_stride, ptr_t dense,
+           int64_t dense_stride, int nd, ptr_t w, int64_t B, ptr_t emb_out, int64_t emb_stride, ptr_t fm_out,
+           ptr_t ws, ptr_t oob, ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_fm_f32(d.data(), (int32_t)d.size(), P<const void>(ids), ids_dtype, ids_stride,
+                                  P<const float>(dense), dense_stride, nd, P<const float>(w), B,
+                                  P<float>(emb_out), emb_stride, P<float>(fm_out), P<float>(ws),
+                                  P<int32_t>(oob), P<void>(stream)),
+                "rec_gather_fm_f32");
+        });
+
   m.def("cross_f32", [](ptr_t x, int64_t x_stride, int dim, ptr_t w, ptr_t b, int L, int64_t B,
                         ptr_t out, int64_t out_stride, ptr_t stream) {
     py::gil_scoped_release nogil;

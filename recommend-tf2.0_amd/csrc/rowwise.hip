@@ -100,6 +100,75 @@ __global__ __launch_bounds__(256) void fm_layer_finish_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1+K3 fused (DeepFM): LPR = D/4 lanes own a sample, stream its F rows (16 B per lane, 8 loads in
+// flight), copy them into the concat buffer and keep s = sum x, q = sum x^2, lin = sum x w in fp64.
+// The batch-global first-order scalar is finished by fm_layer_finish_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int LPR, int IDS_F32>
+__global__ __launch_bounds__(256) void gather_fm_kernel(TableSet ts, const void* __restrict__ ids,
+                                                        int64_t ids_stride, int F,
+                                                        const float* __restrict__ dense, int64_t dense_stride,
+                                                        int nd, const float* __restrict__ w, int64_t B,
+                                                        float* __restrict__ emb_out, int64_t emb_stride,
+                                                        float* __restrict__ fm_out, double* __restrict__ partial,
+                                                        int* __restrict__ oob) {
+  constexpr int D = LPR * 4;
+  constexpr int SPW = 64 / LPR;
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int sl = lane % LPR, sw = lane / LPR;
+  const int64_t b_raw = ((int64_t)blockIdx.x * 4 + wv) * SPW + sw;
+  const bool live = b_raw < B;
+  const int64_t b = live ? b_raw : B - 1;
+  double s = 0.0, q = 0.0, lin = 0.0;
+  constexpr int U = 8;
+  for (int f0 = 0; f0 < F; f0 += U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u < F ? f0 + u : F - 1;
+      const int32_t id = load_id<IDS_F32>(ids, b * ids_stride + f);
+      const bool ok = (uint32_t)id < (uint32_t)ts.vocab[f];
+      if (!ok && oob && live) *oob = 1;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(ts.base[f] + (int64_t)(ok ? id : 0) * D + sl * 4);
+      v[u] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u;
+      if (f < F) {
+        const int oc = ts.out_col[f] + sl * 4;
+        if (live) *reinterpret_cast<f32x4*>(emb_out + b * emb_stride + oc) = v[u];
+        const f32x4 wv4 = *reinterpret_cast<const f32x4*>(w + nd + f * D + sl * 4);  // host checks nd % 4 == 0
+        s += (double)v[u].x + (double)v[u].y + (double)v[u].z + (double)v[u].w;
+        q = fma((double)v[u].x, (double)v[u].x, q);
+        q = fma((double)v[u].y, (double)v[u].y, q);
+        q = fma((double)v[u].z, (double)v[u].z, q);
+        q = fma((double)v[u].w, (double)v[u].w, q);
+        lin = fma((double)v[u].x, (double)wv4.x, lin);
+        lin = fma((double)v[u].y, (double)wv4.y, lin);
+        lin = fma((double)v[u].z, (double)wv4.z, lin);
+        lin = fma((double)v[u].w, (double)wv4.w, lin);
+      }
+    }
+  }
+  // dense part of the first-order term: lanes of the group stride over the nd dense columns
+  for (int d0 = sl; d0 < nd; d0 += LPR) lin = fma((double)dense[b * dense_stride + d0], (double)w[d0], lin);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (live && sl == 0) fm_out[b] = (float)(0.5 * (s * s - q));
+  double lin_w = live ? lin : 0.0;
+  lin_w = wave_sum_f64(lin_w);
+  if (lane == 0) wsum[wv] = lin_w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4 — CrossNetwork: x0 and x_l of one row live in VGPRs (VPL float4 per lane, dim <= 256*VPL);
 // per layer one wave-wide dot (shuffle reduce) and one AXPY; w_l / b_l stream from L2.
 // ------------------------------------------------------------------------------------------------
@@ -421,8 +490,11 @@ extern "C" int rec_dice_f32(const float* x, const float* alpha, const float* mea
 }
 
 extern "C" int64_t rec_fm_layer_workspace_floats(int64_t B) {
-  (void)B;
-  return 2 * kFmMaxPartials + 2;  // kFmMaxPartials fp64 block partials (+ alignment slack)
+  // fp64 block partials: rec_fm_layer_f32 uses <= kFmMaxPartials, the fused rec_gather_fm_f32 one per
+  // workgroup (>= 4 samples each), + alignment slack
+  int64_t n = (B + 3) / 4;
+  if (n < kFmMaxPartials) n = kFmMaxPartials;
+  return 2 * n + 2;
 }
 
 extern "C" int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_t L1, const float* w,
@@ -444,6 +516,54 @@ extern "C" int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_
   REC_CHECK_LAUNCH(who);
   hipLaunchKernelGGL(fm_layer_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st,
                      partial, (int)blocks, B, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+namespace rec { int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const char* who); }
+
+extern "C" int rec_gather_fm_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                                 int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
+                                 const float* w, int64_t B, float* emb_out, int64_t emb_stride,
+                                 float* fm_out, float* workspace, int32_t* oob_flag, void* stream) {
+  const char* who = "rec_gather_fm_f32";
+  TableSet ts;
+  int rc = fill_table_set(tables, F, &ts, who);
+  if (rc != REC_OK) return rc;
+  const int D = tables[0].dim;
+  const int lpr = D / 4;
+  REC_CHECK_ARG(D % 4 == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0, REC_ESHAPE,
+                "%s: D=%d (need D/4 a power of two <= 64)", who, D);
+  for (int f = 0; f < F; ++f)
+    REC_CHECK_ARG(tables[f].dim == D && aligned16(tables[f].base) && tables[f].out_col % 4 == 0, REC_ESHAPE,
+                  "%s: tables must share dim, be 16-B aligned, out_col %% 4 == 0", who);
+  REC_CHECK_ARG(ids_dtype == REC_IDS_I32 || ids_dtype == REC_IDS_F32, REC_EINVAL, "%s: bad ids_dtype", who);
+  REC_CHECK_ARG(B >= 0 && nd >= 0 && ids_stride >= F, REC_ESHAPE, "%s: bad shape", who);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(ids && w && emb_out && fm_out && workspace && (nd == 0 || dense), REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(aligned16(emb_out) && emb_stride % 4 == 0 && nd % 4 == 0 && aligned16(w), REC_EINVAL,
+                "%s: emb_out must be 16-B aligned with stride %% 4 == 0; w 16-B aligned and nd %% 4 == 0 "
+                "(pad the dense block of w / the concat buffer)", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int spw = 64 / lpr;
+  const int64_t waves = (B + spw - 1) / spw;
+  const int64_t blocks = (waves + 3) / 4;
+  REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "%s: batch too large", who);
+  double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 7) & ~(uintptr_t)7);
+#define REC_GFM(L_)                                                                                        \
+  case L_:                                                                                                 \
+    if (ids_dtype == REC_IDS_F32)                                                                          \
+      hipLaunchKernelGGL((gather_fm_kernel<L_, 1>), dim3((unsigned)blocks), dim3(256), 0, st, ts, ids, ids_stride, \
+                         F, dense, dense_stride, nd, w, B, emb_out, emb_stride, fm_out, partial, oob_flag); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((gather_fm_kernel<L_, 0>), dim3((unsigned)blocks), dim3(256), 0, st, ts, ids, ids_stride, \
+                         F, dense, dense_stride, nd, w, B, emb_out, emb_stride, fm_out, partial, oob_flag); \
+    break;
+  switch (lpr) { REC_GFM(1) REC_GFM(2) REC_GFM(4) REC_GFM(8) REC_GFM(16) REC_GFM(32) REC_GFM(64) }
+#undef REC_GFM
+  REC_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL(fm_layer_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, partial,
+                     (int)blocks, B, fm_out);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }

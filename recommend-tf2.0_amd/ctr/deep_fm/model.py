@@ -36,6 +36,10 @@ class DeepFM(Model):
         self.width = (c + 3) // 4 * 4
         self._group = ops.TableGroup([self.embed_layers['embed_%d' % i].table
                                       for i in range(len(self.sparse_feature_columns))], out_cols=cols)
+        dims = set(self._group.dims)
+        d0 = self._group.dims[0]
+        self._fused_fm = (len(dims) == 1 and d0 % 4 == 0 and (d0 // 4) & (d0 // 4 - 1) == 0 and d0 <= 256)
+        self._w_pad = None
 
     def call(self, inputs, **kwargs):
         dense_inputs, sparse_inputs = inputs
@@ -43,10 +47,22 @@ class DeepFM(Model):
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
         B = sparse_inputs.shape[0]
         buf = torch.empty((B, self.width), dtype=torch.float32, device=self.device)
+        if self.pad:
+            buf[:, :self.pad] = 0.0                                             # pad columns of the dense block
         buf[:, self.pad:self.pad + self.nd] = dense_inputs                      # dense part of the concat
-        ops.gather_concat(self._group, sparse_inputs, out=buf)                  # :53 (sparse part)
         embeds = buf[:, self.pad:self.pad + self.feature_length]               # :56
         sparse_embed = buf[:, self.pad + self.nd:self.pad + self.feature_length]
-        fm_outputs = self.fm([embeds, sparse_embed])                           # :59
+        if self._fused_fm:
+            # one pass: rows -> concat buffer, and the FM layer's sums on the fly (no re-read)
+            key = self.fm._version
+            if self._w_pad is None or self._w_pad[0] != key:
+                wp = torch.zeros(self.pad + self.feature_length, dtype=torch.float32, device=self.device)
+                wp[self.pad:] = self.fm._w['w'].reshape(-1)
+                self._w_pad = (key, wp)
+            fm_outputs = ops.gather_fm(self._group, sparse_inputs, buf[:, :self.pad + self.nd], self._w_pad[1],
+                                       self.pad + self.nd, buf)               # :53 + :59
+        else:
+            ops.gather_concat(self._group, sparse_inputs, out=buf)              # :53 (sparse part)
+            fm_outputs = self.fm([embeds, sparse_embed])                       # :59
         deep_outputs = self.dense(self.dnn(embeds))                            # :61-62
         return ops.add_sigmoid(fm_outputs, deep_outputs)                       # :64

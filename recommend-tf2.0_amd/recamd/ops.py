@@ -163,6 +163,15 @@ def _act_id(act) -> int:
 _fm_ws = {}
 
 
+def _fm_workspace(device, B: int) -> torch.Tensor:
+    need = C.fm_layer_workspace_floats(B)
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _fm_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _fm_ws[key] = torch.empty(need, dtype=torch.float32, device=device)
+    return ws
+
+
 def fm_layer(first: torch.Tensor, second: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """FM layer of DeepFM (src/ctr/layers/modules.py:57-72): first (B,L1), second (B,M), w (L1[,1])
     -> (B,1).  The first-order term is ONE scalar summed over the whole batch (modules.py:65)."""
@@ -173,10 +182,7 @@ def fm_layer(first: torch.Tensor, second: torch.Tensor, w: torch.Tensor) -> torc
     if second.shape[0] != B or w.numel() != L1 or not w.is_contiguous():
         raise ValueError("fm_layer: inconsistent shapes")
     out = torch.empty((B, 1), dtype=torch.float32, device=first.device)
-    key = (first.device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _fm_ws.get(key)
-    if ws is None:
-        ws = _fm_ws[key] = torch.empty(C.fm_layer_workspace_floats(B), dtype=torch.float32, device=first.device)
+    ws = _fm_workspace(first.device, B)
     C.fm_layer_f32(first.data_ptr(), first.stride(0), L1, w.data_ptr(), second.data_ptr(), second.stride(0),
                    second.shape[1], B, out.data_ptr(), ws.data_ptr(), _stream())
     return out
@@ -427,3 +433,21 @@ def gather_din_attention_pool(q, group: TableGroup, ids, mask, W, bias, act="sig
                                1 if mask_from_ids else 0, W.data_ptr(), _chk(bias, "bias").data_ptr(), _ptr(alpha),
                                _act_id(act), B, T, out.data_ptr(), _ptr(oob_flag), _stream())
     return out
+
+
+def gather_fm(group: TableGroup, ids: torch.Tensor, dense: Optional[torch.Tensor], w_padded: torch.Tensor, nd_padded: int,
+              emb_out: torch.Tensor, oob_flag=None) -> torch.Tensor:
+    """Fused K1+K3 (DeepFM): gathers into the concat buffer `emb_out` (group.out_cols) and returns the FM
+    layer output (B,1) computed in the same pass.  `dense` is the (B, nd_padded) dense block AS STORED in
+    the concat buffer (zero-padded to a multiple of 4 columns), `w_padded` = FM weights in the same
+    padded concat order (pad entries multiply zeros)."""
+    ids = _rows2d(_chk(ids, "ids", None), "ids")
+    _rows2d(_chk(emb_out, "emb_out"), "emb_out")
+    B = ids.shape[0]
+    w_padded = _chk(w_padded, "w").reshape(-1)
+    fm_out = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
+    ws = _fm_workspace(ids.device, B)
+    C.gather_fm_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0), _ptr(dense),
+                    dense.stride(0) if dense is not None else 0, nd_padded, w_padded.data_ptr(), B, emb_out.data_ptr(),
+                    emb_out.stride(0), fm_out.data_ptr(), ws.data_ptr(), _ptr(oob_flag), _stream())
+    return fm_out

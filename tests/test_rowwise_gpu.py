@@ -120,3 +120,27 @@ def test_gather_dot_scores(dev, B, n, d):
     exp = np.sum(seq[:, None, :].astype(np.float64) * emb, axis=-1)
     assert close(out, exp)
     assert int(flag.item()) == (1 if B > 5 else 0)
+
+
+@pytest.mark.parametrize("B,F,D,nd", [(1, 3, 4, 0), (300, 26, 8, 13), (1000, 26, 128, 13), (77, 5, 16, 4), (4100, 26, 64, 13), (33, 2, 256, 1)])
+def test_gather_fm_fused(dev, B, F, D, nd):
+    """Fused K1+K3 == gather_concat followed by the FM layer (oracle), and the gathered rows are bit-exact."""
+    from recamd import ops
+    rng = np.random.default_rng(B + F + D)
+    vocabs = [int(v) for v in rng.integers(3, 200, size=F)]
+    tables = [(rng.normal(size=(v, D)) * 0.1).astype(np.float32) for v in vocabs]
+    ids = np.stack([rng.integers(-1, v + 1, size=B) for v in vocabs], axis=1).astype(np.int32)
+    dense = rng.random((B, nd)).astype(np.float32)
+    w = (rng.normal(size=(nd + F * D, 1)) * 0.05).astype(np.float32)
+    pad = (-nd) % 4
+    cols = [pad + nd + f * D for f in range(F)]
+    g = ops.TableGroup([T(t, dev) for t in tables], out_cols=cols)
+    buf = torch.zeros((B, pad + nd + F * D), device=dev)
+    buf[:, pad:pad + nd] = T(dense, dev)
+    wp = np.zeros(pad + nd + F * D, np.float32)
+    wp[pad:] = w[:, 0]
+    out = ops.gather_fm(g, T(ids, dev), buf[:, :pad + nd], T(wp, dev), pad + nd, buf).cpu().numpy()
+    emb = ref.gather_concat(tables, ids, oob="zero")
+    assert np.array_equal(buf[:, pad + nd:].cpu().numpy(), emb)
+    first = np.concatenate([dense, emb], axis=1)
+    assert close(out, ref.fm_layer(first, emb, w))
