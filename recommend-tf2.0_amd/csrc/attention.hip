@@ -742,6 +742,9 @@ bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, c
 // ================================================================================================
 namespace rec {
 
+// NTc / KSc > 0: compile-time field-tile count and din/4 (full unrolling lets the compiler batch the
+// ds_reads ahead of each MFMA chain); 0 = runtime values
+template <int NTc, int KSc>
 __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restrict__ xq,
                                                            const float* __restrict__ xk,
                                                            const float* __restrict__ xv, int64_t B, int N,
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HS = H * S;
   const int NP = (N + 15) & ~15;   // padded field count
-  const int NT = NP >> 4;
+  const int NT = NTc > 0 ? NTc : (NP >> 4);
   const int LDX = din + 1;         // X row stride (bank spread for the row-per-lane operand reads)
   const int LDQ = HS + 1;
   // block-shared weights [4][din][HS]
@@ -787,16 +790,18 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
   const float* Xk = nx == 3 ? Xs + NP * LDX : Xs;
   const float* Xv = nx == 3 ? Xs + 2 * NP * LDX : Xs;
   const int lr = lane & 15, g = lane >> 4;
-  const int ksteps = din >> 2;
+  const int ksteps = KSc > 0 ? KSc : (din >> 2);
 
   // ---- projections Q, K, V -> LDS
   for (int m = 0; m < 3; ++m) {
     const float* X = m == 0 ? Xq : (m == 1 ? Xk : Xv);
     const float* Wm = Wsh + m * wsz;
     float* dst = m == 0 ? Qs : (m == 1 ? Ks : Vs);
+#pragma unroll
     for (int rt = 0; rt < NT; ++rt)
       for (int ct = 0; ct < H; ++ct) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int st = 0; st < ksteps; ++st) {
           const float a = X[(rt * 16 + lr) * LDX + 4 * st + g];
           const float bw = Wm[(4 * st + g) * HS + ct * 16 + lr];
@@ -811,6 +816,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
 
   const float scale = 4.0f * 1.4426950408889634f;  // "/ (S ** -0.5)" = x sqrt(16), folded with log2(e)
   for (int h = 0; h < H; ++h)
+#pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       // ---- transposed scores for this query tile against every key tile (NT <= 4)
       f32x4 sc[4];
@@ -864,6 +870,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
       if (W0) {
         f32x4 rr = {0.f, 0.f, 0.f, 0.f};
         const float* W0s = Wsh + 3 * wsz;
+#pragma unroll
         for (int st = 0; st < ksteps; ++st) {
           const float a = W0s[(4 * st + g) * HS + h * 16 + lr];
           const float bx = Xv[(qt * 16 + lr) * LDX + 4 * st + g];
@@ -886,13 +893,22 @@ bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, in
   const size_t floats = (size_t)4 * din * HS + (size_t)4 * ((size_t)nx * NP * (din + 1) + (size_t)3 * NP * (HS + 1));
   const size_t lds = floats * sizeof(float);
   if (lds > 160 * 1024) return false;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(mha_ctr_mfma_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return false;
-  hipLaunchKernelGGL(mha_ctr_mfma_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, st, xq, xk, xv, B, N, din,
-                     Wq, Wk, Wv, W0, H, act, nx, out);
-  return true;
+  const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define REC_CTR(NT_, KS_)                                                                                   \
+  {                                                                                                         \
+    if (lds > 64 * 1024 &&                                                                                  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mha_ctr_mfma_kernel<NT_, KS_>),                   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)            \
+      return false;                                                                                         \
+    hipLaunchKernelGGL((mha_ctr_mfma_kernel<NT_, KS_>), grid, block, lds, st, xq, xk, xv, B, N, din, Wq, Wk, \
+                       Wv, W0, H, act, nx, out);                                                            \
+    return true;                                                                                            \
+  }
+  if (NP == 48 && din == 16) REC_CTR(3, 4)      // 39 fields x dim 16 (BASELINE config 3, layer 1)
+  if (NP == 48 && din == 32) REC_CTR(3, 8)      // layers 2.. (H*S = 32 inputs)
+  if (NP == 32 && din == 16) REC_CTR(2, 4)      // 26 sparse fields only
+  REC_CTR(0, 0)
+#undef REC_CTR
 }
 
 }  // namespace rec
