@@ -7,6 +7,8 @@
 // All are HBM-bound streaming reductions: every input element is read exactly once, rows are read
 // with 16-B vector loads where the address allows (scalar head/tail otherwise), reductions are
 // wavefront shuffles, no LDS.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rec {
@@ -222,6 +224,91 @@ __global__ __launch_bounds__(256) void cross_kernel(const float* __restrict__ x,
   for (int v = 0; v < VPL; ++v) {
     const int idx = lane + 64 * v;
     if (idx < nvec) po[idx] = xl[v];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4, closed form.  x_{l+1} = x0 (x_l . w_l) + b_l + x_l unrolls to x_l = alpha_l x0 + beta_l with
+//   beta_l = b_0 + ... + b_{l-1}  (row independent),   s_l = alpha_l (x0 . w_l) + (beta_l . w_l),
+//   alpha_{l+1} = alpha_l + s_l,  alpha_0 = 1.
+// So a row needs L INDEPENDENT dots of x0 (no serial dependence through x_l), a scalar recurrence and
+// one AXPY: x0 is the only per-row tile in VGPRs (half the registers of the literal form, twice the
+// occupancy), w_l streams from L2 once per row instead of w_l and b_l, beta_L sits in LDS.
+// Same value in exact arithmetic; fp32 rounding differs at the 1e-7 level (parity bar 1e-5).
+// ------------------------------------------------------------------------------------------------
+constexpr int kCrossMaxL = 8;
+
+template <int VPL>
+__global__ __launch_bounds__(256) void cross_closed_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                           int dim, const float* __restrict__ w,
+                                                           const float* __restrict__ bv, int L, int64_t B,
+                                                           float* __restrict__ out, int64_t out_stride) {
+  extern __shared__ __attribute__((aligned(16))) float beta[];  // beta_L, dim floats
+  __shared__ float cdot[kCrossMaxL];                             // beta_l . w_l
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int nvec = dim >> 2;
+  // ---- block prologue: beta_L and the L constants c_l = beta_l . w_l (wave l computes c_l)
+  for (int c = tid; c < dim; c += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += bv[(int64_t)l * dim + c];
+    beta[c] = acc;
+  }
+  for (int l = wv; l < L; l += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+      float bl = 0.f;
+      for (int k2 = 0; k2 < l; ++k2) bl += bv[(int64_t)k2 * dim + c];
+      acc = fmaf(bl, w[(int64_t)l * dim + c], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) cdot[l] = acc;
+  }
+  __syncthreads();
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < B; b += nwaves) {
+    f32x4 x0[VPL];
+    const f32x4* px = reinterpret_cast<const f32x4*>(x + b * x_stride);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int idx = lane + 64 * v;
+      x0[v] = idx < nvec ? px[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float alpha = 1.f;
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {  // not unrolled: one layer's w tile in flight at a time (VGPR budget)
+      const f32x4* pw = reinterpret_cast<const f32x4*>(w + (int64_t)l * dim);
+      float acc = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int idx = lane + 64 * v;
+        if (idx < nvec) {
+          const f32x4 wv4 = pw[idx];
+          acc = fmaf(x0[v].x, wv4.x, acc);
+          acc = fmaf(x0[v].y, wv4.y, acc);
+          acc = fmaf(x0[v].z, wv4.z, acc);
+          acc = fmaf(x0[v].w, wv4.w, acc);
+        }
+      }
+      acc = wave_sum(acc);
+      alpha += fmaf(alpha, acc, cdot[l]);
+    }
+    f32x4* po = reinterpret_cast<f32x4*>(out + b * out_stride);
+    const f32x4* pb = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int idx = lane + 64 * v;
+      if (idx < nvec) {
+        const f32x4 bb = pb[idx];
+        f32x4 r;
+        r.x = fmaf(alpha, x0[v].x, bb.x);
+        r.y = fmaf(alpha, x0[v].y, bb.y);
+        r.z = fmaf(alpha, x0[v].z, bb.z);
+        r.w = fmaf(alpha, x0[v].w, bb.w);
+        po[idx] = r;
+      }
+    }
   }
 }
 
@@ -582,6 +669,23 @@ extern "C" int rec_cross_f32(const float* x, int64_t x_stride, int32_t dim, cons
                    x_stride % 4 == 0 && out_stride % 4 == 0 && dim <= 4096;
   if (vec) {
     const int vpl = (dim / 4 + 63) / 64;
+    const bool literal = getenv("REC_CROSS_IMPL") && getenv("REC_CROSS_IMPL")[0] == 'l';  // A/B only
+    if (!literal && L >= 1 && L <= kCrossMaxL) {
+      int64_t blocks = (B + 3) / 4;
+      int bpc = 4;  // 102 VGPRs -> 4 waves/SIMD = 4 workgroups per CU resident (measured 4/6/8: 0.466/0.523/0.513 ms)
+      if (const char* e = getenv("REC_CROSS_BPC")) bpc = atoi(e) > 0 ? atoi(e) : bpc;
+      if (blocks > 256 * bpc) blocks = 256 * bpc;  // persistent: the prologue runs once per workgroup
+      const size_t lds = (size_t)dim * sizeof(float);
+#define REC_CROSS_C(V)                                                                                \
+  if (vpl <= V) {                                                                                     \
+    hipLaunchKernelGGL((cross_closed_kernel<V>), dim3((unsigned)blocks), block, lds, st, x, x_stride, dim, w, b, \
+                       L, B, out, out_stride);                                                        \
+    REC_CHECK_LAUNCH(who);                                                                            \
+    return REC_OK;                                                                                    \
+  }
+      REC_CROSS_C(1) REC_CROSS_C(2) REC_CROSS_C(4) REC_CROSS_C(8) REC_CROSS_C(13) REC_CROSS_C(16)
+#undef REC_CROSS_C
+    }
 #define REC_CROSS(V)                                                                            \
   if (vpl <= V) {                                                                               \
     hipLaunchKernelGGL((cross_kernel<V>), grid, block, 0, st, x, x_stride, dim, w, b, L, B, out, \
