@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
   const int NP = (N + 15) & ~15;   // padded field count
   const int NT = NTc > 0 ? NTc : (NP >> 4);
   const int LDX = din + 1;         // X row stride (bank spread for the row-per-lane operand reads)
-  const int LDQ = HS + 1;
+  const int LDQ = S + 1;           // per-head Q/K/V tiles: 2+ workgroups fit a CU's LDS
   // block-shared weights [4][din][HS]
   float* Wsh = lds;
   const int wsz = din * HS;
@@ -792,30 +792,26 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
   const int lr = lane & 15, g = lane >> 4;
   const int ksteps = KSc > 0 ? KSc : (din >> 2);
 
-  // ---- projections Q, K, V -> LDS
-  for (int m = 0; m < 3; ++m) {
-    const float* X = m == 0 ? Xq : (m == 1 ? Xk : Xv);
-    const float* Wm = Wsh + m * wsz;
-    float* dst = m == 0 ? Qs : (m == 1 ? Ks : Vs);
+  const float scale = 4.0f * 1.4426950408889634f;  // "/ (S ** -0.5)" = x sqrt(16), folded with log2(e)
+  for (int h = 0; h < H; ++h) {
+    // ---- projections of head h: Q_h, K_h, V_h = act(X W[:, 16h:16h+16]) -> wave-private LDS
+    for (int m = 0; m < 3; ++m) {
+      const float* X = m == 0 ? Xq : (m == 1 ? Xk : Xv);
+      const float* Wm = Wsh + m * wsz;
+      float* dst = m == 0 ? Qs : (m == 1 ? Ks : Vs);
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt)
-      for (int ct = 0; ct < H; ++ct) {
+      for (int rt = 0; rt < NT; ++rt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < ksteps; ++st) {
           const float a = X[(rt * 16 + lr) * LDX + 4 * st + g];
-          const float bw = Wm[(4 * st + g) * HS + ct * 16 + lr];
+          const float bw = Wm[(4 * st + g) * HS + h * 16 + lr];
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          dst[(rt * 16 + 4 * g + r) * LDQ + ct * 16 + lr] = act_apply(acc[r], act, 0.f);
+        for (int r = 0; r < 4; ++r) dst[(rt * 16 + 4 * g + r) * LDQ + lr] = act_apply(acc[r], act, 0.f);
       }
-  }
-  // wave-private LDS: the wave's own ds ops are ordered, no barrier needed
-
-  const float scale = 4.0f * 1.4426950408889634f;  // "/ (S ** -0.5)" = x sqrt(16), folded with log2(e)
-  for (int h = 0; h < H; ++h)
+    }
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       // ---- transposed scores for this query tile against every key tile (NT <= 4)
@@ -828,8 +824,8 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int st = 0; st < 4; ++st) {
-            const float a = Ks[(kt * 16 + lr) * LDQ + h * 16 + 4 * st + g];
-            const float bq = Qs[(qt * 16 + lr) * LDQ + h * 16 + 4 * st + g];
+            const float a = Ks[(kt * 16 + lr) * LDQ + 4 * st + g];
+            const float bq = Qs[(qt * 16 + lr) * LDQ + 4 * st + g];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
           }
 #pragma unroll
@@ -862,7 +858,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
         if (kt < NT) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float a = Vs[(kt * 16 + 4 * g + r) * LDQ + h * 16 + lr];
+            const float a = Vs[(kt * 16 + 4 * g + r) * LDQ + lr];
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sc[kt][r] * inv, o, 0, 0, 0);
           }
         }
@@ -882,6 +878,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
       const int qi = qt * 16 + lr;
       if (qi < N) *reinterpret_cast<f32x4*>(out + (b * N + qi) * (int64_t)HS + h * 16 + 4 * g) = o;
     }
+  }
 }
 
 bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
@@ -890,7 +887,7 @@ bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, in
   if (S != 16 || N > 64 || din % 4 != 0 || din > 256 || !aligned16(out)) return false;
   const int nx = (xq == xk && xk == xv) ? 1 : 3;
   const int HS = H * 16, NP = (N + 15) & ~15;
-  const size_t floats = (size_t)4 * din * HS + (size_t)4 * ((size_t)nx * NP * (din + 1) + (size_t)3 * NP * (HS + 1));
+  const size_t floats = (size_t)4 * din * HS + (size_t)4 * ((size_t)nx * NP * (din + 1) + (size_t)3 * NP * (16 + 1));
   const size_t lds = floats * sizeof(float);
   if (lds > 160 * 1024) return false;
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
