@@ -437,6 +437,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// d % 4 == 0, d/4 a power of two <= 64: LPR = d/4 lanes own a row (16 B each), 64/LPR rows per wave
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ r,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ row_mask, int64_t rows,
+                                                            float* __restrict__ out) {
+  constexpr int D = LPR * 4;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane % LPR, sub = lane / LPR;
+  const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const bool live = row_raw < rows;
+  const int64_t row = live ? row_raw : rows - 1;
+  f32x4 v = reinterpret_cast<const f32x4*>(x + row * D)[sl];
+  if (r) v += reinterpret_cast<const f32x4*>(r + row * D)[sl];
+  float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mu = s / (float)D;
+  const f32x4 c = v - mu;
+  float q = c.x * c.x;
+  q = fmaf(c.y, c.y, q);
+  q = fmaf(c.z, c.z, q);
+  q = fmaf(c.w, c.w, q);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float inv = 1.f / sqrtf(q / (float)D + eps);
+  const float m = row_mask ? row_mask[row] : 1.f;
+  const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[sl];
+  const f32x4 b = reinterpret_cast<const f32x4*>(beta)[sl];
+  const f32x4 y = (c * inv * g + b) * m;
+  if (live) reinterpret_cast<f32x4*>(out + row * D)[sl] = y;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K10 — out[b, j] = seq_info[b] . table[ids[b, j]]; LPR = d/4 lanes per looked-up row
 // ------------------------------------------------------------------------------------------------
@@ -741,6 +777,21 @@ extern "C" int rec_layernorm_residual_f32(const float* x, const float* r, const 
                 (long long)rows, d);
   if (rows == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int lpr = d / 4;
+  if (d % 4 == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && aligned16(x) && aligned16(out) && aligned16(gamma) &&
+      aligned16(beta) && (!r || aligned16(r))) {
+#define REC_LN(L_)                                                                                         \
+  case L_: {                                                                                               \
+    const int64_t waves = (rows + (64 / L_) - 1) / (64 / L_);                                              \
+    hipLaunchKernelGGL((layernorm_vec_kernel<L_>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, r, \
+                       gamma, beta, eps, row_mask, rows, out);                                             \
+    break;                                                                                                 \
+  }
+    switch (lpr) { REC_LN(1) REC_LN(2) REC_LN(4) REC_LN(8) REC_LN(16) REC_LN(32) REC_LN(64) }
+#undef REC_LN
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, r,
                      gamma, beta, eps, row_mask, rows, d, out);
   REC_CHECK_LAUNCH(who);

@@ -49,8 +49,10 @@ class SASRec(Model):
         seq_inputs, pos_inputs, neg_inputs = [to_device_ids(t, self.device) for t in inputs]
         B, S = seq_inputs.shape
         mask = (seq_inputs != 0).to(torch.float32)                                        # :72 (B,S)
-        seq_embed = self.user_embed_layers['embed_seq_item'](seq_inputs)                  # :75 (B,S,d)
-        att_outputs = ops.scale_rows(seq_embed, mask)                                     # :81-82
+        # :75 + :81-82 in one pass: `seq_embed * mask` zeroes exactly the rows whose id is 0, so pad ids
+        # are sent to the gather as out-of-range (-1) and read as zero rows (finite tables: identical)
+        seq_m = torch.where(seq_inputs == 0, torch.full_like(seq_inputs, -1), seq_inputs)
+        att_outputs = self.user_embed_layers['embed_seq_item'](seq_m)                     # (B,S,d)
         nb = len(self.encoder_layer)
         seq_info = None
         for i, block in enumerate(self.encoder_layer):
