@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
                                                            float* __restrict__ out, int64_t out_stride) {
   constexpr int LDW = NT * 32;
   constexpr int LDO = NT * 32 + 4;  // output staging row stride (16-B aligned rows, bank spread)
+  constexpr int LDA = 2 * KH + 4;   // x tile row stride
+  // the per-wave LDS region serves both the x tile (K <= 64 only) and, later, the output tile
+  constexpr int LDT = (KH <= 32 && LDA > LDO) ? LDA : LDO;
   extern __shared__ __attribute__((aligned(16))) float Ws[];  // [K][LDW], zero padded columns
-  float* Ot = Ws + (size_t)K * LDW;                           // [4 waves][32][LDO]
+  float* Ot = Ws + (size_t)K * LDW;                           // [4 waves][32][LDT]
   const bool staged = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) && (out_stride % 4 == 0);
   const int tid = threadIdx.x;
   for (int e = tid; e < K * LDW; e += 256) {
@@ -161,17 +164,46 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   constexpr int kh = KH;  // K == 2*KH exactly (dispatch): no runtime guards inside the MFMA loop
   for (int64_t t = (int64_t)blockIdx.x * 4 + wv; t < ntiles; t += nwaves) {
-    const int64_t row = t * 32 + rl;
-    const int64_t rc = row < M ? row : M - 1;
     float a[KH];
-    const f32x4* xp = reinterpret_cast<const f32x4*>(x + rc * x_stride + hf * kh);
+    if constexpr (KH > 32) {
+      // K = 128: row-per-lane 16-B loads straight into the operand registers (measured faster than the
+      // LDS transpose at this width: 0.434 vs 0.525 ms at 1.6M x 128 x 64)
+      int64_t grow = t * 32 + rl;
+      grow = grow < M ? grow : M - 1;
+      const f32x4* xp = reinterpret_cast<const f32x4*>(x + grow * x_stride + hf * kh);
 #pragma unroll
-    for (int c = 0; c < KH / 4; ++c) {
-      const f32x4 v = xp[c];
-      a[4 * c] = v.x;
-      a[4 * c + 1] = v.y;
-      a[4 * c + 2] = v.z;
-      a[4 * c + 3] = v.w;
+      for (int c = 0; c < KH / 4; ++c) {
+        const f32x4 v = xp[c];
+        a[4 * c] = v.x;
+        a[4 * c + 1] = v.y;
+        a[4 * c + 2] = v.z;
+        a[4 * c + 3] = v.w;
+      }
+    } else {
+      // x tile (32 rows x K) -> LDS with fully coalesced 16-B loads (K/4 lanes per row), then each lane
+      // reads ITS row's half in MFMA operand order (row stride K+4 floats: conflict-free ds_read_b128)
+      constexpr int K = 2 * KH;
+      constexpr int LPRW = K / 4;          // lanes per row
+      constexpr int RPI = 64 / LPRW;       // rows per wave-instruction
+      float* at = Ot + wv * (32 * LDT);
+      const int lr = lane / LPRW, lc = lane % LPRW;
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int rr = i * RPI + lr;
+        int64_t grow = t * 32 + rr;
+        grow = grow < M ? grow : M - 1;
+        const f32x4 v = reinterpret_cast<const f32x4*>(x + grow * x_stride)[lc];
+        *reinterpret_cast<f32x4*>(at + rr * LDA + lc * 4) = v;
+      }
+      const f32x4* ap = reinterpret_cast<const f32x4*>(at + rl * LDA + hf * kh);
+#pragma unroll
+      for (int c = 0; c < KH / 4; ++c) {
+        const f32x4 v = ap[c];
+        a[4 * c] = v.x;
+        a[4 * c + 1] = v.y;
+        a[4 * c + 2] = v.z;
+        a[4 * c + 3] = v.w;
+      }
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
     if (staged) {
       // 4-B-per-lane stores are the slow path on this part (see pairwise_dot.hip): stage the 32 x N tile in
       // a wave-private LDS region and write 16 B per lane, whole rows at a time
-      float* ot = Ot + wv * (32 * LDO);
+      float* ot = Ot + wv * (32 * LDT);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int col = j * 32 + rl;
@@ -228,7 +260,8 @@ template <int KH, int NT>
 static void launch_skinny(const float* x, int64_t x_stride, const float* W, const float* bias,
                           const float* alpha, int act, int64_t M, int K, int N, float* out,
                           int64_t out_stride, hipStream_t st) {
-  const size_t lds = ((size_t)K * NT * 32 + (size_t)4 * 32 * (NT * 32 + 4)) * sizeof(float);
+  const int ldt = (KH <= 32 && (2 * KH + 4) > (NT * 32 + 4)) ? (2 * KH + 4) : (NT * 32 + 4);
+  const size_t lds = ((size_t)K * NT * 32 + (size_t)4 * 32 * ldt) * sizeof(float);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_skinny_kernel<KH, NT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
