@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
                                                            const float* __restrict__ W,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ alpha, int act,
-                                                           int64_t M, int K, int N,
+                                                           int64_t M, int K, int N, int w_stride,
                                                            float* __restrict__ out, int64_t out_stride) {
   constexpr int LDW = NT * 32;
   constexpr int LDO = NT * 32 + 4;  // output staging row stride (16-B aligned rows, bank spread)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
   const int tid = threadIdx.x;
   for (int e = tid; e < K * LDW; e += 256) {
     const int kk = e / LDW, n = e - kk * LDW;
-    Ws[e] = n < N ? W[(int64_t)kk * N + n] : 0.f;
+    Ws[e] = n < N ? W[(int64_t)kk * w_stride + n] : 0.f;
   }
   __syncthreads();
   const int lane = tid & 63;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(const float* __restri
 
 template <int KH, int NT>
 static void launch_skinny(const float* x, int64_t x_stride, const float* W, const float* bias,
-                          const float* alpha, int act, int64_t M, int K, int N, float* out,
+                          const float* alpha, int act, int64_t M, int K, int N, int w_stride, float* out,
                           int64_t out_stride, hipStream_t st) {
   const int ldt = (KH <= 32 && (2 * KH + 4) > (NT * 32 + 4)) ? (2 * KH + 4) : (NT * 32 + 4);
   const size_t lds = ((size_t)K * NT * 32 + (size_t)4 * 32 * ldt) * sizeof(float);
@@ -269,7 +269,7 @@ static void launch_skinny(const float* x, int64_t x_stride, const float* W, cons
   int64_t blocks = (ntiles + 3) / 4;
   if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: W is staged once per workgroup
   hipLaunchKernelGGL((dense_skinny_kernel<KH, NT>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_stride, W,
-                     bias, alpha, act, M, K, N, out, out_stride);
+                     bias, alpha, act, M, K, N, w_stride, out, out_stride);
 }
 
 }  // namespace rec
@@ -287,21 +287,28 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
   if (M == 0) return REC_OK;
   REC_CHECK_ARG(x && W && out, REC_EINVAL, "%s: NULL pointer", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool skinny = N > 8 && N <= 64 && (K == 16 || K == 32 || K == 64 || K == 128) && M >= 256 && aligned16(x) &&
+  const bool skinny = N > 8 && N <= 128 && (N <= 64 || (N - 64) % 4 == 0) && (K == 16 || K == 32 || K == 64 || K == 128) && M >= 256 && aligned16(x) &&
                       x_stride % 4 == 0 && !(getenv("REC_DENSE_IMPL") && getenv("REC_DENSE_IMPL")[0] == 't');
   if (skinny) {
-    const int nt = (N + 31) / 32;
-#define REC_SK(KH_, NT_)                                                                        \
-  if (K / 2 == KH_ && nt == NT_) {                                                              \
-    launch_skinny<KH_, NT_>(x, x_stride, W, bias, alpha, act, M, K, N, out, out_stride, st);    \
-    REC_CHECK_LAUNCH(who);                                                                      \
-    return REC_OK;                                                                              \
+    // N in (64, 128]: two column halves (x is read twice, still ahead of the tiled kernel at these widths)
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      const int nn = N - n0 < 64 ? N - n0 : 64;
+      const int nt = (nn + 31) / 32;
+      const float* Wp = W + n0;
+      const float* bp = bias ? bias + n0 : nullptr;
+      const float* ap = alpha ? alpha + n0 : nullptr;
+      float* op = out + n0;
+      bool done = false;
+#define REC_SK(KH_, NT_)                                                                              \
+  if (!done && K / 2 == KH_ && nt == NT_) {                                                           \
+    launch_skinny<KH_, NT_>(x, x_stride, Wp, bp, ap, act, M, K, nn, N, op, out_stride, st);           \
+    done = true;                                                                                      \
   }
-    REC_SK(8, 1) REC_SK(8, 2) REC_SK(8, 3) REC_SK(8, 4)
-    REC_SK(16, 1) REC_SK(16, 2) REC_SK(16, 3) REC_SK(16, 4)
-    REC_SK(32, 1) REC_SK(32, 2) REC_SK(32, 3) REC_SK(32, 4)
-    REC_SK(64, 1) REC_SK(64, 2) REC_SK(64, 3) REC_SK(64, 4)
+      REC_SK(8, 1) REC_SK(8, 2) REC_SK(16, 1) REC_SK(16, 2) REC_SK(32, 1) REC_SK(32, 2) REC_SK(64, 1) REC_SK(64, 2)
 #undef REC_SK
+      REC_CHECK_LAUNCH(who);
+    }
+    return REC_OK;
   }
   if (N <= 8) {
     hipLaunchKernelGGL((dense_narrow_kernel<8>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x,
