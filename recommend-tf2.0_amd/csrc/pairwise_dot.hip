@@ -294,6 +294,14 @@ bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, i
                               int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
                               int append_dense, int* oob, hipStream_t st);
 
+bool pairdot128_pipe_dispatch(const TableSet& ts, bool has_dense, int ids_f32, int n, const void* ids,
+                              int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
+                              int64_t out_stride, int append_dense, int* oob, hipStream_t st);
+static bool use_pipe() {
+  const char* e = getenv("REC_PAIRDOT_IMPL");
+  return e && e[0] == 'p';
+}
+
 // REC_PAIRDOT_IMPL=mfma selects the matrix-core variant for D = 128 (pairwise_dot_mfma.hip); it is
 // parity-green but currently latency-bound (247 us vs 231 us at 65 536 x 27 x 128, round 1), so
 // the register-tiled VALU kernel below stays the default.  A/B measurements only.
@@ -404,6 +412,12 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D == 128 && use_pipe() &&
+      pairdot128_pipe_dispatch(ts, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids, ids_stride, dense,
+                               dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (D == 128 && use_mfma() &&
       pairdot128_mfma_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids,
                                ids_stride, dense, dense_stride, B, out, out_stride, append_dense,
