@@ -214,6 +214,25 @@ int rec_scale_rows_f32(const float* x, const float* row_scale, int64_t rows, int
 int rec_dice_f32(const float* x, const float* alpha, const float* mean, const float* var, float eps,
                  int64_t rows, int32_t d, float* out, void* stream);
 
+/* ---- §8f-1 (next row after the path): embedding backward + optimiser step ---------------------------
+ * TF computes the gradient of tf.gather as IndexedSlices and Keras' Adam applies it as
+ *   m = b1 m + (1-b1) g,  v = b2 v + (1-b2) g^2  over ALL rows (g = 0 for untouched rows),
+ *   var -= lr_t m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t) / (1-b1^t)
+ * (every train script, e.g. src/ctr/fm/train.py:49; Adam defaults b1 .9, b2 .999, eps 1e-7), and the
+ * `embeddings_regularizer=l2(c)` of every model (e.g. src/ctr/dlrm/model.py:35) adds the DENSE
+ * gradient 2 c var.  So the exact step is: scatter-add the sparse row gradients (duplicates summed) into a
+ * dense (V, D) accumulator, then one dense Adam pass that also adds the L2 term.
+ *
+ * rec_embedding_grad_f32: grads[f].base[ids[b, f], :] += dy[b, grads[f].out_col : +dim_f]  (fp32 atomics:
+ *   the sum over duplicate ids is order-dependent in the last bits).  Out-of-range ids are skipped. */
+int rec_embedding_grad_f32(const rec_table_desc* grads, int32_t F, const void* ids, int32_t ids_dtype,
+                           int64_t ids_stride, const float* dy, int64_t dy_stride, int64_t B,
+                           void* stream);
+/* Dense Adam step over n contiguous elements (one table or a whole arena); l2 = regulariser
+ * coefficient c (0 = none); step = t >= 1.  grad is read-only (the caller zeroes it for the next step). */
+int rec_adam_f32(float* var, float* m, float* v, const float* grad, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int64_t step, float l2, void* stream);
+
 /* ---- C2: row-sharded lookup helpers (exchange itself = RCCL all-to-all issued by the host) --
  * Bucket a flat id list by owner rank for cyclic row sharding (owner = id % G, local = id / G):
  *   counts[g]      = number of ids owned by g             (device int32[G], zeroed by the call)

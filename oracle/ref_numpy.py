@@ -447,3 +447,33 @@ def youtube_dnn_towers(user_ids, user_tables, item_ids, item_tables, user_layers
         emb = np.concatenate([embedding_lookup(np.asarray(t, dtype), i) for i, t in zip(ids_list, tables)], axis=-1)
         return dnn_match(emb, layers, act, dtype)
     return tower(user_ids, user_tables, user_layers), tower(item_ids, item_tables, item_layers)
+
+
+# --------------------------------------------------------------------------------------------
+# §8f-1 — embedding backward and the Keras Adam step (the step after the hot path)
+# --------------------------------------------------------------------------------------------
+def embedding_grad(ids, dy, vocabs, dims, dtype=np.float64):
+    """Gradient of gather_concat w.r.t. the tables: IndexedSlices of tf.gather densified — rows of dy are
+    scatter-ADDED at their ids (duplicates sum), out-of-range ids contribute nothing."""
+    ids = cast_ids(ids)
+    dy = np.asarray(dy, dtype)
+    grads, col = [], 0
+    for f, (V, D) in enumerate(zip(vocabs, dims)):
+        g = np.zeros((V, D), dtype)
+        ok = (ids[:, f] >= 0) & (ids[:, f] < V)
+        np.add.at(g, ids[ok, f], dy[ok, col:col + D])
+        grads.append(g)
+        col += D
+    return grads
+
+
+def adam_step(var, m, v, grad, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, l2=0.0, dtype=np.float64):
+    """tf.keras.optimizers.Adam (TF2.x, amsgrad=False) dense update; `embeddings_regularizer=l2(c)` adds
+    c * sum(w^2) to the loss, i.e. 2 c w to the gradient.  Returns (var, m, v)."""
+    var, m, v, grad = (np.asarray(a, dtype) for a in (var, m, v, grad))
+    g = grad + 2.0 * l2 * var
+    lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    var = var - lr_t * m / (np.sqrt(v) + eps)
+    return var, m, v

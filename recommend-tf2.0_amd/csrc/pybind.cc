@@ -212,6 +212,23 @@ PYBIND11_MODULE(_C, m) {
           "rec_dice_f32");
   });
 
+  m.def("embedding_grad_f32",
+        [](const std::vector<TableTuple>& grads, ptr_t ids, int ids_dtype, int64_t ids_stride, ptr_t dy,
+           int64_t dy_stride, int64_t B, ptr_t stream) {
+          auto d = to_descs(grads);
+          py::gil_scoped_release nogil;
+          check(rec_embedding_grad_f32(d.data(), (int32_t)d.size(), P<const void>(ids), ids_dtype, ids_stride,
+                                       P<const float>(dy), dy_stride, B, P<void>(stream)),
+                "rec_embedding_grad_f32");
+        });
+  m.def("adam_f32", [](ptr_t var, ptr_t mm, ptr_t vv, ptr_t grad, int64_t n, float lr, float b1, float b2,
+                       float eps, int64_t step, float l2, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_adam_f32(P<float>(var), P<float>(mm), P<float>(vv), P<const float>(grad), n, lr, b1, b2, eps, step,
+                       l2, P<void>(stream)),
+          "rec_adam_f32");
+  });
+
   m.def("shard_bucket_workspace_bytes",
         [](int64_t n, int G) { return rec_shard_bucket_workspace_bytes(n, G); });
   m.def("shard_bucket_i32", [](ptr_t ids, int64_t n, int G, ptr_t counts, ptr_t perm,

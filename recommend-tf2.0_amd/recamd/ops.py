@@ -451,3 +451,28 @@ def gather_fm(group: TableGroup, ids: torch.Tensor, dense: Optional[torch.Tensor
                     dense.stride(0) if dense is not None else 0, nd_padded, w_padded.data_ptr(), B, emb_out.data_ptr(),
                     emb_out.stride(0), fm_out.data_ptr(), ws.data_ptr(), _ptr(oob_flag), _stream())
     return fm_out
+
+
+def embedding_grad(grad_group: TableGroup, ids: torch.Tensor, dy: torch.Tensor) -> None:
+    """Backward of gather_concat: grad_tables[f][ids[b,f]] += dy[b, out_col_f : +D_f] (duplicates summed;
+    TF's IndexedSlices gradient of tf.gather).  `grad_group` wraps the (V_f, D_f) fp32 accumulators."""
+    ids = _rows2d(_chk(ids, "ids", None), "ids")
+    _rows2d(_chk(dy, "dy"), "dy")
+    B, F = ids.shape
+    if F != len(grad_group) or dy.shape[0] != B or dy.shape[1] < grad_group.width:
+        raise ValueError("embedding_grad: inconsistent shapes")
+    for lo in range(0, F, C.MAX_TABLES):
+        hi = min(F, lo + C.MAX_TABLES)
+        C.embedding_grad_f32(grad_group.descs[lo:hi], ids[:, lo:hi].data_ptr(), _ids_dtype(ids), ids.stride(0),
+                             dy.data_ptr(), dy.stride(0), B, _stream())
+
+
+def adam_step(var: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor, step: int, lr: float = 1e-3,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7, l2: float = 0.0) -> None:
+    """In-place dense Keras-Adam update (TF2 defaults) with the embeddings' l2(c) regulariser gradient 2 c var."""
+    for t, nm in ((var, "var"), (m, "m"), (v, "v"), (grad, "grad")):
+        _chk(t, nm)
+        if not t.is_contiguous() or t.numel() != var.numel():
+            raise ValueError(f"{nm}: must be contiguous and match var")
+    C.adam_f32(var.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), var.numel(), float(lr), float(beta1),
+               float(beta2), float(eps), int(step), float(l2), _stream())
