@@ -297,6 +297,14 @@ bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, i
 bool pairdot128_pipe_dispatch(const TableSet& ts, bool has_dense, int ids_f32, int n, const void* ids,
                               int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
                               int64_t out_stride, int append_dense, int* oob, hipStream_t st);
+bool pairdot128_gram_dispatch(const TableSet& ts, int F, bool has_dense, int ids_f32, const void* ids,
+                              int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
+                              int64_t out_stride, int append_dense, int* oob, hipStream_t st);
+// REC_PAIRDOT_IMPL=gram: bf16x3 matrix-core kernel (pairwise_dot_gram.hip)
+static bool use_gram() {
+  const char* e = getenv("REC_PAIRDOT_IMPL");
+  return e && e[0] == 'g';
+}
 static bool use_pipe() {
   const char* e = getenv("REC_PAIRDOT_IMPL");
   return e && e[0] == 'p';
@@ -412,6 +420,12 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D == 128 && use_gram() &&
+      pairdot128_gram_dispatch(ts, F, dense != nullptr, ids_dtype == REC_IDS_F32, ids, ids_stride, dense,
+                               dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (D == 128 && use_pipe() &&
       pairdot128_pipe_dispatch(ts, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids, ids_stride, dense,
                                dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {

@@ -1,0 +1,95 @@
+// Experiment: loads-only persistent kernel in the gram kernel's row-per-lane layout, W waves per SIMD, T tiles
+// (13.8 KB samples) in flight per wave.  Predicts what each register budget can reach before any compute.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const f4 __attribute__((address_space(1)))* gptr;
+__device__ __attribute__((aligned(512))) float g_zero[128];
+
+template <int T, int W>
+__global__ __launch_bounds__(256, W) void k_persist(const float* arena, int64_t V, const int* ids, const float* dense,
+                                                    int B, float* sink, int chunk, int burst, float* outp, int smode_) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  extern __shared__ float dyn_lds[];
+  int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  if (chunk > 0) {  // one-shot waves, `chunk` strided samples each: pretend the grid is the first B/chunk waves
+    nw = (B + chunk - 1) / chunk;
+    if (wave >= nw) return;
+  }
+  auto ptr = [&](int b) -> gptr {
+    const float* p = g_zero;
+    if (b < B) {
+      if (r < 26) p = arena + ((int64_t)r * V + ids[(int64_t)b * 26 + r]) * 128;
+      else if (r == 26) p = dense + (int64_t)b * 128;
+    }
+    return (gptr)(uintptr_t)(p + h * 8);
+  };
+  f4 x[T][16];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    gptr q = ptr(wave + t * nw);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { x[t][2 * s] = q[4 * s]; x[t][2 * s + 1] = q[4 * s + 1]; }
+  }
+  f4 acc = {0, 0, 0, 0};
+  for (int b = wave; b < B; b += nw * T) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      gptr q = ptr(b + (t + T) * nw);
+      if (burst) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += x[t][s];
+        asm volatile("" : "+v"(acc));
+        if (outp) {
+          const int bcur = b + t * nw;
+          const int smode = smode_;
+          const int64_t stride = (smode == 3 || smode == 6) ? 512 : 480;
+          f4* orow = (f4*)(outp + (int64_t)bcur * stride);
+          if (smode == 7) orow = (f4*)(outp + ((int64_t)wave * ((B + nw - 1) / nw) + (bcur / nw)) * 480);
+          if (smode == 4) {
+            orow[lane] = acc;
+            orow[lane + 64 < 120 ? lane + 64 : 119] = acc;
+          } else if (smode == 2) {
+            __builtin_nontemporal_store(acc, orow + lane);
+            if (lane < 56) __builtin_nontemporal_store(acc, orow + lane + 64);
+          } else if (smode == 5) {
+            __builtin_nontemporal_store(acc, orow + lane);
+          } else if (smode == 6) {
+            __builtin_nontemporal_store(acc, orow + lane);
+            __builtin_nontemporal_store(acc, orow + lane + 64);
+          } else {
+            __builtin_nontemporal_store(acc, orow + lane);
+            __builtin_nontemporal_store(acc, orow + (lane + 64 < 120 ? lane + 64 : 119));
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { x[t][2 * s] = q[4 * s]; x[t][2 * s + 1] = q[4 * s + 1]; }
+      } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc += x[t][2 * s];
+        acc += x[t][2 * s + 1];
+        asm volatile("" : "+v"(acc));
+        x[t][2 * s] = q[4 * s];
+        x[t][2 * s + 1] = q[4 * s + 1];
+      }
+      }
+    }
+  }
+  float tt = acc.x + acc.y + acc.z + acc.w;
+  if (tt == 12345.678f) sink[wave] = tt;
+}
+
+#define LAUNCH(T_, W_)                                                                                        \
+  if (T == T_ && W == W_) {                                                                                   \
+    int grid = (chunk & 0xffff) > 0 ? (((B + (chunk & 0xffff) - 1) / (chunk & 0xffff)) + 3) / 4 : 256 * W_;                                    \
+    hipLaunchKernelGGL((k_persist<T_, W_>), dim3(grid), dim3(256), lds, st, arena, V, ids, dense, B, sink, chunk & 0xffff, (chunk >> 16) & 1, (chunk >> 17) ? outp : nullptr, chunk >> 17); \
+    return (int)hipGetLastError();                                                                            \
+  }
+extern "C" int run(int T, int W, const float* arena, int64_t V, const int* ids, const float* dense, int B, float* sink,
+                   void* stream, int lds, int chunk, float* outp) {
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH(1, 2) LAUNCH(1, 3) LAUNCH(1, 4) LAUNCH(1, 5) LAUNCH(1, 6) LAUNCH(2, 2) LAUNCH(2, 3) LAUNCH(3, 2) LAUNCH(1, 7)
+  LAUNCH(3, 1) LAUNCH(6, 1) LAUNCH(2, 1)
+  return -1;
+}
