@@ -80,6 +80,49 @@ __global__ __launch_bounds__(256, W) void k_persist(const float* arena, int64_t 
   if (tt == 12345.678f) sink[wave] = tt;
 }
 
+// role split: in every block waves 0..2 only load (bursts, T = 1), wave 3 only stores the 1 920-B output rows of
+// the block's samples (no synchronisation between them: this measures the memory system, not a pipeline)
+__global__ __launch_bounds__(256, 3) void k_roles(const float* arena, int64_t V, const int* ids, const float* dense,
+                                                  int B, float* sink, float* outp) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
+  const int nblk = gridDim.x;
+  if (w == 3) {
+    f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (int b = blockIdx.x; b < B; b += nblk) {
+      f4* orow = (f4*)(outp + (int64_t)b * 480);
+      __builtin_nontemporal_store(v, orow + lane);
+      if (lane < 56) __builtin_nontemporal_store(v, orow + lane + 64);
+    }
+    return;
+  }
+  const int wave = blockIdx.x * 3 + w, nw = nblk * 3;
+  auto ptr = [&](int b) -> gptr {
+    const float* p = g_zero;
+    if (b < B) {
+      if (r < 26) p = arena + ((int64_t)r * V + ids[(int64_t)b * 26 + r]) * 128;
+      else if (r == 26) p = dense + (int64_t)b * 128;
+    }
+    return (gptr)(uintptr_t)(p + h * 8);
+  };
+  f4 x[16];
+  {
+    gptr q = ptr(wave);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { x[2 * s] = q[4 * s]; x[2 * s + 1] = q[4 * s + 1]; }
+  }
+  f4 acc = {0, 0, 0, 0};
+  for (int b = wave; b < B; b += nw) {
+    gptr q = ptr(b + nw);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc += x[s];
+    asm volatile("" : "+v"(acc));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { x[2 * s] = q[4 * s]; x[2 * s + 1] = q[4 * s + 1]; }
+  }
+  float tt = acc.x + acc.y + acc.z + acc.w;
+  if (tt == 12345.678f) sink[wave] = tt;
+}
+
 #define LAUNCH(T_, W_)                                                                                        \
   if (T == T_ && W == W_) {                                                                                   \
     int grid = (chunk & 0xffff) > 0 ? (((B + (chunk & 0xffff) - 1) / (chunk & 0xffff)) + 3) / 4 : 256 * W_;                                    \
@@ -89,6 +132,10 @@ __global__ __launch_bounds__(256, W) void k_persist(const float* arena, int64_t 
 extern "C" int run(int T, int W, const float* arena, int64_t V, const int* ids, const float* dense, int B, float* sink,
                    void* stream, int lds, int chunk, float* outp) {
   hipStream_t st = (hipStream_t)stream;
+  if (T == 0) {  // role-split kernel, W blocks per CU
+    hipLaunchKernelGGL(k_roles, dim3(256 * W), dim3(256), 0, st, arena, V, ids, dense, B, sink, outp);
+    return (int)hipGetLastError();
+  }
   LAUNCH(1, 2) LAUNCH(1, 3) LAUNCH(1, 4) LAUNCH(1, 5) LAUNCH(1, 6) LAUNCH(2, 2) LAUNCH(2, 3) LAUNCH(3, 2) LAUNCH(1, 7)
   LAUNCH(3, 1) LAUNCH(6, 1) LAUNCH(2, 1)
   return -1;
