@@ -205,6 +205,11 @@ int rec_gather_dot_scores_f32(const float* seq_info, int64_t seq_stride,
  * out[i] = sigmoid(a[i] + b[i]) (b may be NULL): tf.nn.sigmoid(tf.add(fm_outputs, deep_outputs))
  * src/ctr/deep_fm/model.py:64 and the final sigmoids of dcn/model.py:56, dlrm/model.py:53. */
 int rec_add_sigmoid_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* out[i] = act(alpha * a[i] + beta * b[i]), act in {none, relu, sigmoid, tanh}:  `relu(x + inputs)` of
+ * Residual_Units (src/ctr/layers/modules.py:33) and `sigmoid(0.5 * wide_out + 0.5 * deep_out)` of
+ * src/ctr/wide_deep/model.py:78. */
+int rec_axpby_act_f32(const float* a, float alpha, const float* b, float beta, int64_t n, int32_t act,
+                      float* out, void* stream);
 /* out[r, :] = x[r, :] * row_scale[r]:  `att_outputs *= mask`, src/match/sasrec/model.py:82 */
 int rec_scale_rows_f32(const float* x, const float* row_scale, int64_t rows, int32_t d, float* out,
                        void* stream);

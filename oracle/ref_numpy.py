@@ -477,3 +477,45 @@ def adam_step(var, m, v, grad, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, 
     v = beta2 * v + (1.0 - beta2) * g * g
     var = var - lr_t * m / (np.sqrt(v) + eps)
     return var, m, v
+
+
+# --------------------------------------------------------------------------------------------
+# §8f-4 — zoo models that reuse the a1 lookup: Deep&Crossing, Wide&Deep, ESMM
+# --------------------------------------------------------------------------------------------
+def residual_unit(x, W1, b1, W2, b2, dtype=np.float64):
+    """src/ctr/layers/modules.py:29-34: relu(Dense2(relu(Dense1(x))) + x)."""
+    x = np.asarray(x, dtype)
+    h = dense(dense(x, np.asarray(W1, dtype), np.asarray(b1, dtype), "relu"), np.asarray(W2, dtype), np.asarray(b2, dtype))
+    return np.maximum(h + x, 0)
+
+
+def deep_crossing_forward(ids, tables, res_units, final, dtype=np.float64):
+    """src/ctr/deep_crossing/model.py:42-51.  res_units: list of (W1, b1, W2, b2)."""
+    r = gather_concat([np.asarray(t, dtype) for t in tables], ids)
+    for W1, b1, W2, b2 in res_units:
+        r = residual_unit(r, W1, b1, W2, b2, dtype)
+    return sigmoid(dense(r, np.asarray(final[0], dtype), np.asarray(final[1], dtype)))
+
+
+def wide_deep_forward(dense_in, ids, tables, linear, dnn_layers, final, act="relu", dtype=np.float64):
+    """src/ctr/wide_deep/model.py:66-79: sigmoid(0.5 * Linear(dense) + 0.5 * Dense(DNN([emb, dense])))."""
+    dense_in = np.asarray(dense_in, dtype)
+    emb = gather_concat([np.asarray(t, dtype) for t in tables], ids)
+    x = np.concatenate([emb, dense_in], axis=-1)
+    wide = dense(dense_in, np.asarray(linear[0], dtype), np.asarray(linear[1], dtype))
+    deep = dense(dnn_match(x, dnn_layers, act, dtype), np.asarray(final[0], dtype), np.asarray(final[1], dtype))
+    return sigmoid(0.5 * wide + 0.5 * deep)
+
+
+def esmm_tower(user_num, user_cate, item_num, item_cate, user_tables, user_cols, item_tables, item_cols,
+               user_dnn, item_dnn, head, act="relu", dtype=np.float64):
+    """src/ctr/esmm/model.py:42-73 (one tower).  *_cate are float id matrices (Keras cast);
+    head = dict(bn=..., dense=(W, b), out=(W, b))."""
+    ue = gather_concat([np.asarray(t, dtype) for t in user_tables], np.asarray(user_cate)[:, user_cols])
+    ie = gather_concat([np.asarray(t, dtype) for t in item_tables], np.asarray(item_cate)[:, item_cols])
+    uf = dnn_ctr(np.concatenate([np.asarray(user_num, dtype), ue], axis=-1), user_dnn["layers"], act, user_dnn.get("bn"), dtype)
+    itf = dnn_ctr(np.concatenate([np.asarray(item_num, dtype), ie], axis=-1), item_dnn["layers"], act, item_dnn.get("bn"), dtype)
+    x = np.concatenate([uf, itf], axis=-1)
+    x = batch_norm_inference(x, **{k: np.asarray(v, dtype) for k, v in head["bn"].items()})
+    x = dense(x, np.asarray(head["dense"][0], dtype), np.asarray(head["dense"][1], dtype), "relu")
+    return sigmoid(dense(x, np.asarray(head["out"][0], dtype), np.asarray(head["out"][1], dtype)))

@@ -198,6 +198,12 @@ PYBIND11_MODULE(_C, m) {
     check(rec_add_sigmoid_f32(P<const float>(a), P<const float>(b), n, P<float>(out), P<void>(stream)),
           "rec_add_sigmoid_f32");
   });
+  m.def("axpby_act_f32", [](ptr_t a, float alpha, ptr_t b, float beta, int64_t n, int act, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_axpby_act_f32(P<const float>(a), alpha, P<const float>(b), beta, n, act, P<float>(out),
+                            P<void>(stream)),
+          "rec_axpby_act_f32");
+  });
   m.def("scale_rows_f32", [](ptr_t x, ptr_t sc, int64_t rows, int d, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_scale_rows_f32(P<const float>(x), P<const float>(sc), rows, d, P<float>(out),

@@ -535,6 +535,28 @@ __global__ __launch_bounds__(256) void add_sigmoid_kernel(const float* __restric
   if (i < n) out[i] = 1.f / (1.f + expf(-(a[i] + (b ? b[i] : 0.f))));
 }
 
+// out = act(alpha * a + beta * b): residual add + ReLU of Residual_Units, the 0.5/0.5 blend of Wide&Deep
+__global__ __launch_bounds__(256) void axpby_act_kernel(const float* __restrict__ a, float alpha,
+                                                        const float* __restrict__ b, float beta, int64_t n, int act,
+                                                        float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = act_apply(alpha * a[i] + beta * b[i], act, 0.f);
+}
+
+__global__ __launch_bounds__(256) void axpby_act_vec_kernel(const f32x4* __restrict__ a, float alpha,
+                                                            const f32x4* __restrict__ b, float beta, int64_t n4,
+                                                            int act, f32x4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = a[i] * alpha + b[i] * beta;
+  f32x4 o;
+  o.x = act_apply(v.x, act, 0.f);
+  o.y = act_apply(v.y, act, 0.f);
+  o.z = act_apply(v.z, act, 0.f);
+  o.w = act_apply(v.w, act, 0.f);
+  out[i] = o;
+}
+
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ sc, int64_t total,
                                                          int d, float* __restrict__ out) {
@@ -575,6 +597,27 @@ extern "C" int rec_add_sigmoid_f32(const float* a, const float* b, int64_t n, fl
   REC_CHECK_ARG(a && out, REC_EINVAL, "%s: NULL pointer", who);
   hipLaunchKernelGGL(add_sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a, b, n, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_axpby_act_f32(const float* a, float alpha, const float* b, float beta, int64_t n, int32_t act,
+                                 float* out, void* stream) {
+  const char* who = "rec_axpby_act_f32";
+  REC_CHECK_ARG(n >= 0, REC_ESHAPE, "%s: n=%lld", who, (long long)n);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_TANH, REC_EINVAL, "%s: act %d (none/relu/sigmoid/tanh)", who, act);
+  if (n == 0) return REC_OK;
+  REC_CHECK_ARG(a && b && out, REC_EINVAL, "%s: NULL pointer", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((n & 3) == 0 && aligned16(a) && aligned16(b) && aligned16(out)) {
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL(axpby_act_vec_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4*>(a), alpha, reinterpret_cast<const f32x4*>(b), beta, n4, act,
+                       reinterpret_cast<f32x4*>(out));
+  } else {
+    hipLaunchKernelGGL(axpby_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, alpha, b, beta, n,
+                       act, out);
+  }
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }

@@ -1,9 +1,22 @@
-"""Mirror of src/ctr/layers/modules.py: FM, CrossNetwork, DNN, AttentionLayer, MultiHeadAttention,
+"""Mirror of src/ctr/layers/modules.py: Residual_Units, FM, CrossNetwork, DNN, AttentionLayer, MultiHeadAttention,
 Dice — same constructor signatures and `call(inputs)` structure, arithmetic on the HIP kernels."""
 import torch
 
 from recamd import nn, ops
 from recamd.nn import Dice  # noqa: F401  (src/ctr/layers/modules.py:327-337)
+
+
+class Residual_Units(nn.Layer):
+    """src/ctr/layers/modules.py:15-34: Dense(hidden_unit, relu) -> Dense(dim_stack) -> relu(x + inputs)."""
+
+    def __init__(self, hidden_unit, dim_stack):
+        super().__init__()
+        self.layer1 = self.track('layer1', nn.Dense(units=hidden_unit, activation='relu'))
+        self.layer2 = self.track('layer2', nn.Dense(units=dim_stack, activation=None))
+
+    def call(self, inputs, **kwargs):
+        x = self.layer2(self.layer1(inputs))
+        return ops.axpby_act(x, inputs, 1.0, 1.0, 'relu')        # :33
 
 
 class FM(nn.Layer):

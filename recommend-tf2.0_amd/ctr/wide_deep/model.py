@@ -1,0 +1,63 @@
+"""Mirror of src/ctr/wide_deep/model.py (Wide & Deep) on the HIP kernels.  The file defines its own `Linear`
+(:15-23) and a BatchNorm-free `DNN` (:26-46); `feature_columns = [dense_feature_columns, sparse_feature_columns]`."""
+import torch
+
+from recamd import nn, ops
+from recamd.nn import Model, to_device_f32, to_device_ids
+
+
+class Linear(nn.Layer):
+    """wide_deep/model.py:15-23: Dense(1)."""
+
+    def __init__(self):
+        super().__init__()
+        self.dense = self.track('dense', nn.Dense(1, activation=None))
+
+    def call(self, inputs, **kwargs):
+        return self.dense(inputs)
+
+
+class DNN(nn.Layer):
+    """wide_deep/model.py:26-46: Dense stack + Dropout (no BatchNormalization, unlike ctr.layers.modules.DNN)."""
+
+    def __init__(self, hidden_units, activation='relu', dropout=0.):
+        super().__init__()
+        self.dnn_network = [self.track(f'dense_{i}', nn.Dense(units=unit, activation=activation))
+                            for i, unit in enumerate(hidden_units)]
+        self.dropout = nn.Dropout(dropout)
+
+    def call(self, inputs, **kwargs):
+        x = inputs
+        for dnn in self.dnn_network:
+            x = dnn(x)
+        return self.dropout(x)
+
+
+class WideDeep(Model):
+    def __init__(self, feature_columns, hidden_units, activation='relu', dnn_dropout=0., embed_reg=1e-4):
+        super().__init__()
+        self.dense_feature_columns, self.sparse_feature_columns = feature_columns
+        self.embed_layers = {
+            'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
+                input_dim=feat['feat_num'], input_length=1, output_dim=feat['embed_dim'],
+                embeddings_initializer='random_uniform'))
+            for i, feat in enumerate(self.sparse_feature_columns)
+        }
+        self.dnn_network = DNN(hidden_units, activation, dnn_dropout)
+        self.linear = Linear()
+        self.final_dense = nn.Dense(1, activation=None)
+        self._group = ops.TableGroup([self.embed_layers['embed_%d' % i].table
+                                      for i in range(len(self.sparse_feature_columns))])
+
+    def call(self, inputs, **kwargs):
+        dense_inputs, sparse_inputs = inputs
+        dense_inputs = to_device_f32(dense_inputs, self.device)
+        sparse_inputs = to_device_ids(sparse_inputs, self.device)
+        # x = concat([sparse_embed, dense_inputs]) (:70): the gather writes straight into the concat buffer
+        B, nd, We = dense_inputs.shape[0], dense_inputs.shape[1], self._group.width
+        x = torch.empty((B, We + nd), dtype=torch.float32, device=self.device)
+        ops.gather_concat(self._group, sparse_inputs, out=x)               # :68-69
+        x[:, We:] = dense_inputs
+        wide_out = self.linear(dense_inputs)                               # :73
+        deep_out = self.final_dense(self.dnn_network(x))                   # :75-76
+        return ops.axpby_act(wide_out, deep_out, 0.5, 0.5, 'sigmoid')      # :78

@@ -387,6 +387,20 @@ def add_sigmoid(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tens
     return out
 
 
+def axpby_act(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, beta: float = 1.0, act=None) -> torch.Tensor:
+    """act(alpha * a + beta * b), elementwise (Residual_Units' relu(x + inputs), Wide&Deep's 0.5/0.5 blend)."""
+    a = _chk(a, "a").contiguous()
+    b = _chk(b, "b").contiguous()
+    if b.shape != a.shape:
+        raise ValueError("axpby_act: shape mismatch")
+    if act == 'prelu':
+        raise ValueError("axpby_act: prelu is not supported here")
+    out = torch.empty_like(a)
+    C.axpby_act_f32(a.data_ptr(), float(alpha), b.data_ptr(), float(beta), a.numel(), _act_id(act), out.data_ptr(),
+                    _stream())
+    return out
+
+
 def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
     """x[..., :] * row_scale[...]  (SASRec `att_outputs *= mask`)."""
     _chk(x, "x")
