@@ -251,6 +251,15 @@ int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, int32_t* coun
 int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,
                            float* out, int64_t out_stride, void* stream);
 
+/* ---- §8f-4: retrieval after the towers — exact inner-product top-k ---------------------------------
+ * Replaces faiss.IndexFlatIP(d).add(items).search(queries, k) of src/match/dssm/dssm_train.py:74-78 and
+ * src/match/fm/train.py:71-75.  queries (Q, d), items (N, d) row-major with the given strides, d <= 128,
+ * k <= 32.  out_scores (Q, k) descending, out_idx (Q, k) int64 row numbers into `items` (faiss labels); equal
+ * scores order by smaller index; with N < k the tail is (-inf, -1). */
+int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
+                    int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
+                    int64_t* out_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

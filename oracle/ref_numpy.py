@@ -519,3 +519,19 @@ def esmm_tower(user_num, user_cate, item_num, item_cate, user_tables, user_cols,
     x = batch_norm_inference(x, **{k: np.asarray(v, dtype) for k, v in head["bn"].items()})
     x = dense(x, np.asarray(head["dense"][0], dtype), np.asarray(head["dense"][1], dtype), "relu")
     return sigmoid(dense(x, np.asarray(head["out"][0], dtype), np.asarray(head["out"][1], dtype)))
+
+
+def topk_inner_product(queries, items, k, dtype=np.float64):
+    """faiss.IndexFlatIP(d).add(items).search(queries, k) (src/match/dssm/dssm_train.py:74-78): exact inner
+    products, k best per query, scores descending; ties -> smaller index (our definition; faiss leaves it open);
+    fewer than k items -> (-inf, -1) padding."""
+    q, it = np.asarray(queries, dtype), np.asarray(items, dtype)
+    Q, N = q.shape[0], it.shape[0]
+    scores = q @ it.T if N else np.zeros((Q, 0), dtype)
+    order = np.argsort(-scores, axis=1, kind="stable")[:, :k]
+    D = np.take_along_axis(scores, order, axis=1)
+    I = order.astype(np.int64)
+    if N < k:
+        D = np.concatenate([D, np.full((Q, k - N), -np.inf, dtype)], axis=1)
+        I = np.concatenate([I, np.full((Q, k - N), -1, np.int64)], axis=1)
+    return D, I

@@ -235,6 +235,14 @@ PYBIND11_MODULE(_C, m) {
           "rec_adam_f32");
   });
 
+  m.def("topk_ip_f32", [](ptr_t q, int64_t q_stride, int64_t Q, ptr_t items, int64_t items_stride, int64_t N, int d,
+                          int k, ptr_t out_scores, ptr_t out_idx, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_topk_ip_f32(P<const float>(q), q_stride, Q, P<const float>(items), items_stride, N, d, k,
+                          P<float>(out_scores), P<int64_t>(out_idx), P<void>(stream)),
+          "rec_topk_ip_f32");
+  });
+
   m.def("shard_bucket_workspace_bytes",
         [](int64_t n, int G) { return rec_shard_bucket_workspace_bytes(n, G); });
   m.def("shard_bucket_i32", [](ptr_t ids, int64_t n, int G, ptr_t counts, ptr_t perm,

@@ -1,0 +1,194 @@
+// §8f-4 — the retrieval step after the two towers: exact inner-product top-k, the job
+// faiss.IndexFlatIP(d).add(items).search(users, 10) does in src/match/dssm/dssm_train.py:74-78 and
+// src/match/fm/train.py:71-75.  GEMM-shaped (Q x N x d), so it runs on the fp32 matrix cores; the Q x N score
+// matrix is never written to HBM.
+//
+// A workgroup owns 128 queries and streams all N items through 128-item tiles:
+//   * the query tile is loaded ONCE into registers in LDS-staging layout (d/2 floats per thread);
+//   * per item tile: 16-wide k-steps through LDS; wave w computes query rows 32w..32w+31 against all 128 items
+//     (1 x 4 v_mfma_f32_32x32x2_f32 tiles), so a row's 128 scores sit in the accumulators of ONE half-wave
+//     (column on the lane, row in the register) and never leave registers;
+//   * per accumulator register (= one query row per half-wave) the 4 scores of a lane are compared with the row's
+//     current k-th best: one ballot, and after the first few tiles almost every row is skipped;
+//   * rows with a candidate merge {running top-k, 128 new scores} by k rounds of half-wave arg-max
+//     ((score, index) pairs, ties -> smaller index, so the result is deterministic).
+// The running lists (k <= 32 per row) live in LDS (32 KiB) and are written once at the end, scores descending;
+// 49 KiB of LDS per workgroup leaves room for 3 workgroups per CU, which is what hides the item-tile loads.
+#include <math.h>
+
+#include "common.h"
+
+namespace rec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace topk {
+constexpr int BM = 128, BN = 128, BK = 16, KMAX = 32;
+constexpr int LDA = BM + 4, LDB = BN + 4;
+constexpr int DMAX = 128;
+// LDS: As, Bs, running scores, running indices
+constexpr size_t lds_bytes() {
+  return (size_t)(BK * LDA + BK * LDB + BM * KMAX) * sizeof(float) + (size_t)BM * KMAX * sizeof(int);
+}
+}  // namespace topk
+
+// a "better" than b: larger score, ties -> smaller index; index -1 (empty) always loses
+__device__ __forceinline__ bool better(float sa, int ia, float sb, int ib) {
+  return sa > sb || (sa == sb && (unsigned)ia < (unsigned)ib);
+}
+
+template <int KS>  // k-steps of 16: d <= 16 * KS
+__global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void topk_ip_kernel(const float* __restrict__ q, int64_t q_stride,
+                                                      const float* __restrict__ items, int64_t items_stride,
+                                                      int64_t Q, int N, int d, int k, float* __restrict__ out_scores,
+                                                      int64_t* __restrict__ out_idx) {
+  using namespace topk;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  __shared__ float run_s[BM * KMAX];
+  __shared__ int run_i[BM * KMAX];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+  for (int e = tid; e < BM * KMAX; e += 256) {
+    run_s[e] = -INFINITY;
+    run_i[e] = -1;
+  }
+
+  // query tile in staging layout: thread (row = tid/2, 8 consecutive k of every 16-wide k-step)
+  const int a_row = tid >> 1, a_k = (tid & 1) * 8;
+  float aq[KS][8];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int64_t gm = m0 + a_row;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = ks * BK + a_k + e;
+      aq[ks][e] = (gm < Q && kk < d) ? q[gm * q_stride + kk] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  for (int n0 = 0; n0 < N; n0 += BN) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float bv[8];
+      {
+        const int gn = n0 + a_row;  // item row staged by this thread (same map as the queries)
+        const float* pb = items + (int64_t)gn * items_stride + ks * BK + a_k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (gn < N && ks * BK + a_k + e < d) ? pb[e] : 0.f;
+      }
+      __syncthreads();  // previous k-step's tiles consumed
+#pragma unroll
+      for (int e = 0; e < 8; ++e) As[(a_k + e) * LDA + a_row] = aq[ks][e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Bs[(a_k + e) * LDB + a_row] = bv[e];
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const int kr = kk + half;
+        const float a = As[kr * LDA + wv * 32 + l32];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[kr * LDB + j * 32 + l32], acc[j], 0, 0, 0);
+      }
+    }
+
+    // top-k update in registers: accumulator register r of half-wave `half` is query row
+    // wv*32 + (r&3) + 8*(r>>2) + 4*half, item columns n0 + 32 j + l32 (j = 0..3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool live = m0 + row < Q;
+      float v[5];
+      int id[5];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = n0 + 32 * j + l32;
+        v[j] = (live && c < N) ? acc[j][r] : -INFINITY;
+        id[j] = (live && c < N) ? c : -1;
+      }
+      const float thr = run_s[row * KMAX + k - 1];
+      const int thr_i = run_i[row * KMAX + k - 1];
+      const bool cand = better(v[0], id[0], thr, thr_i) || better(v[1], id[1], thr, thr_i) ||
+                        better(v[2], id[2], thr, thr_i) || better(v[3], id[3], thr, thr_i);
+      if (!__any(cand)) continue;  // wave-uniform: neither of the two rows of this register has a candidate
+      v[4] = l32 < k ? run_s[row * KMAX + l32] : -INFINITY;
+      id[4] = l32 < k ? run_i[row * KMAX + l32] : -1;
+      float my_s = -INFINITY;
+      int my_i = -1;
+      for (int t = 0; t < k; ++t) {
+        float bs = v[0];
+        int bi = id[0];
+#pragma unroll
+        for (int j = 1; j < 5; ++j)
+          if (better(v[j], id[j], bs, bi)) bs = v[j], bi = id[j];
+        float ws = bs;
+        int wi = bi;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {  // stays inside the 32-lane half
+          const float os = __shfl_xor(ws, off);
+          const int oi = __shfl_xor(wi, off);
+          if (better(os, oi, ws, wi)) ws = os, wi = oi;
+        }
+        if (l32 == t) my_s = ws, my_i = wi;
+        if (wi >= 0 && wi == bi) {  // the owner retires the slot (indices are unique within a row)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (id[j] == wi) v[j] = -INFINITY, id[j] = -1;
+        }
+      }
+      if (l32 < k) {
+        run_s[row * KMAX + l32] = my_s;
+        run_i[row * KMAX + l32] = my_i;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int e = tid; e < BM * k; e += 256) {
+    const int row = e / k, t = e - row * k;
+    if (m0 + row < Q) {
+      out_scores[(m0 + row) * k + t] = run_s[row * KMAX + t];
+      out_idx[(m0 + row) * k + t] = (int64_t)run_i[row * KMAX + t];
+    }
+  }
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
+                               int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
+                               int64_t* out_idx, void* stream) {
+  const char* who = "rec_topk_ip_f32";
+  REC_CHECK_ARG(Q >= 0 && N >= 0 && N <= 0x7fffffffLL, REC_ESHAPE, "%s: Q=%lld N=%lld", who, (long long)Q, (long long)N);
+  REC_CHECK_ARG(d >= 1 && d <= topk::DMAX, REC_ESHAPE, "%s: d=%d (1..%d)", who, d, topk::DMAX);
+  REC_CHECK_ARG(k >= 1 && k <= topk::KMAX, REC_ESHAPE, "%s: k=%d (1..%d)", who, k, topk::KMAX);
+  REC_CHECK_ARG(q_stride >= d && items_stride >= d, REC_ESHAPE, "%s: strides smaller than d", who);
+  if (Q == 0) return REC_OK;
+  REC_CHECK_ARG(queries && out_scores && out_idx && (items || N == 0), REC_EINVAL, "%s: NULL pointer", who);
+  const int64_t blocks = (Q + topk::BM - 1) / topk::BM;
+  REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "%s: too many queries", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define REC_TOPK(KS_)                                                                                           \
+  hipLaunchKernelGGL((topk_ip_kernel<KS_>), dim3((unsigned)blocks), dim3(256), 0, st, queries, q_stride, items, \
+                     items_stride, Q, (int)N, d, k, out_scores, out_idx)
+  if (d <= 16) REC_TOPK(1);
+  else if (d <= 32) REC_TOPK(2);
+  else if (d <= 64) REC_TOPK(4);
+  else REC_TOPK(8);
+#undef REC_TOPK
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}

@@ -490,3 +490,18 @@ def adam_step(var: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.T
             raise ValueError(f"{nm}: must be contiguous and match var")
     C.adam_f32(var.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), var.numel(), float(lr), float(beta1),
                float(beta2), float(eps), int(step), float(l2), _stream())
+
+
+def topk_inner_product(queries: torch.Tensor, items: torch.Tensor, k: int):
+    """Exact inner-product top-k (faiss IndexFlatIP.search): returns (scores (Q,k) descending, idx (Q,k) int64)."""
+    _rows2d(_chk(queries, "queries"), "queries")
+    _rows2d(_chk(items, "items"), "items")
+    Q, d = queries.shape
+    N = items.shape[0]
+    if items.shape[1] != d:
+        raise ValueError("topk_inner_product: queries and items differ in dim")
+    scores = torch.empty((Q, k), dtype=torch.float32, device=queries.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
+    C.topk_ip_f32(queries.data_ptr(), queries.stride(0), Q, items.data_ptr() if N else 0, items.stride(0) if N else d,
+                  N, d, int(k), scores.data_ptr(), idx.data_ptr(), _stream())
+    return scores, idx
