@@ -210,6 +210,15 @@ int rec_add_sigmoid_f32(const float* a, const float* b, int64_t n, float* out, v
  * src/ctr/wide_deep/model.py:78. */
 int rec_axpby_act_f32(const float* a, float alpha, const float* b, float beta, int64_t n, int32_t act,
                       float* out, void* stream);
+/* out[i] = act(a[i] * b[i]):  sigmoid(tf.multiply(gmf_user_embed, gmf_pos_embed)) of src/match/ncf/model.py:53-54,
+ * tf.multiply(ctr_pred, cvr_pred) of src/ctr/esmm/model.py:37. */
+int rec_mul_act_f32(const float* a, const float* b, int64_t n, int32_t act, float* out, void* stream);
+/* Dssm.cosine_similarity (src/match/dssm/model.py:49-62): both tensors flattened to ONE vector (the reshape
+ * (1, -1) makes it a single scalar for the whole batch), out[0] = <a,b> / (|a| |b|), optionally through the
+ * sigmoid of :80.  fp64 accumulation, fixed reduction order (deterministic). */
+int64_t rec_cosine_flat_workspace_bytes(int64_t n);
+int rec_cosine_flat_f32(const float* a, const float* b, int64_t n, int32_t apply_sigmoid, float* out,
+                        void* workspace, void* stream);
 /* out[r, :] = x[r, :] * row_scale[r]:  `att_outputs *= mask`, src/match/sasrec/model.py:82 */
 int rec_scale_rows_f32(const float* x, const float* row_scale, int64_t rows, int32_t d, float* out,
                        void* stream);

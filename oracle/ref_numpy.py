@@ -535,3 +535,31 @@ def topk_inner_product(queries, items, k, dtype=np.float64):
         D = np.concatenate([D, np.full((Q, k - N), -np.inf, dtype)], axis=1)
         I = np.concatenate([I, np.full((Q, k - N), -1, np.int64)], axis=1)
     return D, I
+
+
+def cosine_flat(a, b, dtype=np.float64):
+    """Dssm.cosine_similarity (src/match/dssm/model.py:49-62): both tensors reshaped to (1, -1) -> one scalar."""
+    a, b = np.asarray(a, dtype).reshape(-1), np.asarray(b, dtype).reshape(-1)
+    return np.sum(a * b) / (np.sqrt(np.sum(a * a)) * np.sqrt(np.sum(b * b)))
+
+
+def dssm_forward(user_ids, item_ids, user_tables, item_tables, user_dnn, item_dnn, act="relu", dtype=np.float64):
+    """src/match/dssm/model.py:64-82.  *_ids (B, n_feat) float/int; returns (out (1,1), user_out (B,1,U), item_out)."""
+    u = dnn_match(gather_concat([np.asarray(t, dtype) for t in user_tables], user_ids), user_dnn, act, dtype)[:, None, :]
+    i = dnn_match(gather_concat([np.asarray(t, dtype) for t in item_tables], item_ids), item_dnn, act, dtype)[:, None, :]
+    return sigmoid(np.array([[cosine_flat(i, u, dtype)]])), u, i
+
+
+def ncf_forward(user, pos, neg, user_table, item_table, neg_table, dnn_layers, final, act="relu", dtype=np.float64):
+    """src/match/ncf/model.py:47-80: logits (B, 1 + neg_num)."""
+    ut, it, nt = (np.asarray(t, dtype) for t in (user_table, item_table, neg_table))
+    ue = embedding_lookup(ut, user)                      # (B, 1, dim)
+    W, b = np.asarray(final[0], dtype), np.asarray(final[1], dtype)
+
+    def branch(items):                                   # items (B, T, dim)
+        T = items.shape[1]
+        gmf = sigmoid(ue * items)
+        mlp = dnn_match(np.concatenate([np.tile(ue, (1, T, 1)), items], axis=-1), dnn_layers, act, dtype)
+        return dense(np.concatenate([gmf, mlp], axis=-1), W, b)[..., 0]
+
+    return np.concatenate([branch(embedding_lookup(it, pos)), branch(embedding_lookup(nt, neg))], axis=-1)

@@ -204,6 +204,18 @@ PYBIND11_MODULE(_C, m) {
                             P<void>(stream)),
           "rec_axpby_act_f32");
   });
+  m.def("mul_act_f32", [](ptr_t a, ptr_t b, int64_t n, int act, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_mul_act_f32(P<const float>(a), P<const float>(b), n, act, P<float>(out), P<void>(stream)),
+          "rec_mul_act_f32");
+  });
+  m.def("cosine_flat_workspace_bytes", [](int64_t n) { return rec_cosine_flat_workspace_bytes(n); });
+  m.def("cosine_flat_f32", [](ptr_t a, ptr_t b, int64_t n, int sig, ptr_t out, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_cosine_flat_f32(P<const float>(a), P<const float>(b), n, sig, P<float>(out), P<void>(ws),
+                              P<void>(stream)),
+          "rec_cosine_flat_f32");
+  });
   m.def("scale_rows_f32", [](ptr_t x, ptr_t sc, int64_t rows, int d, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_scale_rows_f32(P<const float>(x), P<const float>(sc), rows, d, P<float>(out),

@@ -557,6 +557,46 @@ __global__ __launch_bounds__(256) void axpby_act_vec_kernel(const f32x4* __restr
   out[i] = o;
 }
 
+// out = act(a * b) elementwise (NCF's sigmoid(user_embed * item_embed), ESMM's pCTR * pCVR)
+__global__ __launch_bounds__(256) void mul_act_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      int64_t n, int act, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = act_apply(a[i] * b[i], act, 0.f);
+}
+
+// cosine over whole flattened tensors: per-block fp64 partials of <a,b>, <a,a>, <b,b>, then a fixed-order finish
+__global__ __launch_bounds__(256) void cosine_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             int64_t n, double* __restrict__ part) {
+  __shared__ double sh[3][4];
+  double ab = 0.0, aa = 0.0, bb = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = a[i], y = b[i];
+    ab += x * y;
+    aa += x * x;
+    bb += y * y;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    ab += __shfl_xor(ab, off);
+    aa += __shfl_xor(aa, off);
+    bb += __shfl_xor(bb, off);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[0][w] = ab, sh[1][w] = aa, sh[2][w] = bb;
+  __syncthreads();
+  if (threadIdx.x < 3)
+    part[(int64_t)blockIdx.x * 3 + threadIdx.x] =
+        sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+__global__ void cosine_finish_kernel(const double* __restrict__ part, int nblk, int apply_sigmoid,
+                                     float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double ab = 0.0, aa = 0.0, bb = 0.0;
+  for (int i = 0; i < nblk; ++i) ab += part[3 * i], aa += part[3 * i + 1], bb += part[3 * i + 2];
+  const double c = ab / (sqrt(aa) * sqrt(bb));
+  out[0] = (float)(apply_sigmoid ? 1.0 / (1.0 + exp(-c)) : c);
+}
+
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ sc, int64_t total,
                                                          int d, float* __restrict__ out) {
@@ -618,6 +658,39 @@ extern "C" int rec_axpby_act_f32(const float* a, float alpha, const float* b, fl
     hipLaunchKernelGGL(axpby_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, alpha, b, beta, n,
                        act, out);
   }
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_mul_act_f32(const float* a, const float* b, int64_t n, int32_t act, float* out, void* stream) {
+  const char* who = "rec_mul_act_f32";
+  REC_CHECK_ARG(n >= 0, REC_ESHAPE, "%s: n=%lld", who, (long long)n);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_TANH, REC_EINVAL, "%s: act %d (none/relu/sigmoid/tanh)", who, act);
+  if (n == 0) return REC_OK;
+  REC_CHECK_ARG(a && b && out, REC_EINVAL, "%s: NULL pointer", who);
+  hipLaunchKernelGGL(mul_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a, b, n, act, out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int64_t rec_cosine_flat_workspace_bytes(int64_t n) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  return blocks * 3 * (int64_t)sizeof(double);
+}
+
+extern "C" int rec_cosine_flat_f32(const float* a, const float* b, int64_t n, int32_t apply_sigmoid, float* out,
+                                   void* workspace, void* stream) {
+  const char* who = "rec_cosine_flat_f32";
+  REC_CHECK_ARG(n >= 1, REC_ESHAPE, "%s: n=%lld", who, (long long)n);
+  REC_CHECK_ARG(a && b && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
+  const int blocks = (int)(rec_cosine_flat_workspace_bytes(n) / (3 * sizeof(double)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cosine_partial_kernel, dim3(blocks), dim3(256), 0, st, a, b, n, static_cast<double*>(workspace));
+  hipLaunchKernelGGL(cosine_finish_kernel, dim3(1), dim3(64), 0, st, static_cast<const double*>(workspace), blocks,
+                     apply_sigmoid, out);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }

@@ -401,6 +401,30 @@ def axpby_act(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, beta: float 
     return out
 
 
+def mul_act(a: torch.Tensor, b: torch.Tensor, act=None) -> torch.Tensor:
+    """act(a * b), elementwise, same shapes (NCF's GMF vector, ESMM's pCTR * pCVR)."""
+    a = _chk(a, "a").contiguous()
+    b = _chk(b, "b").contiguous()
+    if b.shape != a.shape:
+        raise ValueError("mul_act: shape mismatch")
+    out = torch.empty_like(a)
+    C.mul_act_f32(a.data_ptr(), b.data_ptr(), a.numel(), _act_id(act), out.data_ptr(), _stream())
+    return out
+
+
+def cosine_flat(a: torch.Tensor, b: torch.Tensor, sigmoid: bool = False) -> torch.Tensor:
+    """Cosine of the two tensors flattened to single vectors (Dssm.cosine_similarity) -> shape (1,)."""
+    a = _chk(a, "a").contiguous()
+    b = _chk(b, "b").contiguous()
+    if a.numel() != b.numel() or a.numel() == 0:
+        raise ValueError("cosine_flat: tensors must have the same non-zero number of elements")
+    ws = torch.empty(C.cosine_flat_workspace_bytes(a.numel()), dtype=torch.uint8, device=a.device)
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    C.cosine_flat_f32(a.data_ptr(), b.data_ptr(), a.numel(), int(bool(sigmoid)), out.data_ptr(), ws.data_ptr(),
+                      _stream())
+    return out
+
+
 def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
     """x[..., :] * row_scale[...]  (SASRec `att_outputs *= mask`)."""
     _chk(x, "x")

@@ -94,3 +94,70 @@ def test_esmm(dev):
     assert ctr.shape == (B, 1) and ctcvr.shape == (B, 1)
     assert close(ctr, e_ctr)
     assert close(ctcvr, e_ctr * e_cvr)
+
+
+@pytest.mark.parametrize("n", [1, 100, 70_000])
+def test_mul_act_and_cosine_flat(dev, n):
+    from recamd import ops
+    rng = np.random.default_rng(n)
+    a, b = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    assert close(ops.mul_act(ta, tb, 'sigmoid').cpu().numpy(), ref.sigmoid(a.astype(np.float64) * b))
+    assert close(ops.mul_act(ta, tb).cpu().numpy(), a.astype(np.float64) * b)
+    assert close(ops.cosine_flat(ta, tb).cpu().numpy(), np.array([ref.cosine_flat(a, b)]))
+    assert close(ops.cosine_flat(ta, tb, sigmoid=True).cpu().numpy(), ref.sigmoid(np.array([ref.cosine_flat(a, b)])))
+
+
+def match_cols(names, vocabs, D):
+    return [{'feat': n, 'feat_num': v, 'feat_len': 1, 'embed_dim': D} for n, v in zip(names, vocabs)]
+
+
+def test_dssm_towers_and_output(dev):
+    from match.dssm.model import Dssm
+    from recamd.retrieval import IndexFlatIP
+    rng = np.random.default_rng(21)
+    ucols = match_cols(['user_id', 'gender', 'age'], [300, 3, 8], 8)
+    icols = match_cols(['movie_id', 'genre'], [500, 20], 8)
+    m = Dssm(ucols, icols)
+    B = 150
+    uin = {c['feat']: rng.integers(0, c['feat_num'], size=(B, 1)).astype(np.float32) for c in ucols}
+    iin = {c['feat']: rng.integers(0, c['feat_num'], size=(B, 1)).astype(np.float32) for c in icols}
+    m([uin, iin])
+    w = randomize(m, rng, 0.2)
+    out = m([uin, iin]).cpu().numpy()
+    uids = np.concatenate([uin[c['feat']] for c in ucols], axis=1)
+    iids = np.concatenate([iin[c['feat']] for c in icols], axis=1)
+    ut = [w[f"user_embed_{c['feat']}/embeddings"] for c in ucols]
+    it = [w[f"item_embed_{c['feat']}/embeddings"] for c in icols]
+    ud = [(w[f'user_dnn/dense_{i}/kernel'], w[f'user_dnn/dense_{i}/bias']) for i in range(2)]
+    idn = [(w[f'item_dnn/dense_{i}/kernel'], w[f'item_dnn/dense_{i}/bias']) for i in range(2)]
+    e_out, e_u, e_i = ref.dssm_forward(uids, iids, ut, it, ud, idn)
+    assert out.shape == (1, 1)                                       # the whole-batch cosine of the reference
+    assert close(out, e_out)
+    assert close(m.user_dnn_out.cpu().numpy(), e_u) and close(m.item_dnn_out.cpu().numpy(), e_i)
+    # the retrieval step of dssm_train.py:63-78 on the towers
+    index = IndexFlatIP(e_i.shape[-1])
+    index.add(m.item_dnn_out[:, 0, :])
+    D, I = index.search(m.user_dnn_out[:, 0, :], 10)
+    eD, _ = ref.topk_inner_product(e_u[:, 0, :], e_i[:, 0, :], 10)
+    assert np.all(np.abs(D - eD) <= 1e-5 * np.maximum(1.0, np.abs(eD)))
+
+
+@pytest.mark.parametrize("neg", [1, 10])
+def test_ncf(dev, neg):
+    from match.ncf.model import NCF
+    rng = np.random.default_rng(30 + neg)
+    m = NCF({'feat': 'user_id', 'feat_num': 100, 'embed_dim': 8}, {'feat': 'item_id', 'feat_num': 120, 'embed_dim': 8},
+            neg_num=neg)
+    B = 77
+    user = rng.integers(0, 100, size=(B, 1)).astype(np.int32)
+    pos = rng.integers(0, 120, size=(B, 1)).astype(np.int32)
+    negs = rng.integers(0, 120, size=(B, neg)).astype(np.int32)
+    m([user, pos, negs])
+    w = randomize(m, rng, 0.2)
+    out = m([user, pos, negs]).cpu().numpy()
+    layers = [(w[f'dnn/dense_{i}/kernel'], w[f'dnn/dense_{i}/bias']) for i in range(3)]
+    exp = ref.ncf_forward(user, pos, negs, w['user_embedding/embeddings'], w['item_embedding/embeddings'],
+                          w['neg_item_embedding/embeddings'], layers, (w['dense/kernel'], w['dense/bias']))
+    assert out.shape == (B, 1 + neg)
+    assert close(out, exp)
