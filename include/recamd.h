@@ -260,6 +260,17 @@ int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, int32_t* coun
 int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,
                            float* out, int64_t out_stride, void* stream);
 
+/* ---- §8f-2 (first slice): the loss and the metric of every ctr train script --------------------------
+ * model.compile(loss=binary_crossentropy, metrics=[AUC()]) / model.evaluate(...)[1]
+ * (src/ctr/deep_fm/train.py:50-51,68).  y_true, y_pred: n fp32 values (labels 0/1, probabilities).
+ * BCE: Keras epsilon clipping 1e-7, mean over n.  AUC: Keras defaults (200 thresholds, ROC, trapezoid).
+ * workspace: rec_metrics_workspace_bytes(n) bytes of device memory; out: one float. */
+int64_t rec_metrics_workspace_bytes(int64_t n);
+int rec_binary_crossentropy_f32(const float* y_true, const float* y_pred, int64_t n, float* out,
+                                void* workspace, void* stream);
+int rec_auc_f32(const float* y_true, const float* y_pred, int64_t n, float* out, void* workspace,
+                void* stream);
+
 /* ---- §8f-4: retrieval after the towers — exact inner-product top-k ---------------------------------
  * Replaces faiss.IndexFlatIP(d).add(items).search(queries, k) of src/match/dssm/dssm_train.py:74-78 and
  * src/match/fm/train.py:71-75.  queries (Q, d), items (N, d) row-major with the given strides, d <= 128,

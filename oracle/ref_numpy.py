@@ -563,3 +563,30 @@ def ncf_forward(user, pos, neg, user_table, item_table, neg_table, dnn_layers, f
         return dense(np.concatenate([gmf, mlp], axis=-1), W, b)[..., 0]
 
     return np.concatenate([branch(embedding_lookup(it, pos)), branch(embedding_lookup(nt, neg))], axis=-1)
+
+
+# --------------------------------------------------------------------------------------------
+# §8f-2 — loss and metric of the ctr train scripts
+# --------------------------------------------------------------------------------------------
+def binary_crossentropy(y_true, y_pred, eps=1e-7, dtype=np.float64):
+    """tf.keras.losses.binary_crossentropy on probabilities, averaged over all samples
+    (src/ctr/deep_fm/train.py:50): p clipped to [eps, 1-eps]."""
+    y = np.asarray(y_true, dtype).reshape(-1)
+    p = np.clip(np.asarray(y_pred, dtype).reshape(-1), eps, 1.0 - eps)
+    return float(np.mean(-(y * np.log(p) + (1.0 - y) * np.log(1.0 - p))))
+
+
+def keras_auc(y_true, y_pred, num_thresholds=200):
+    """tf.keras.metrics.AUC() defaults (src/ctr/deep_fm/train.py:51): thresholds {0-1e-7, i/(T-1), 1+1e-7} in fp32,
+    `pred > threshold`, ROC, trapezoidal ('interpolation') summation, rates via div_no_nan in fp32."""
+    y = np.asarray(y_true).reshape(-1) != 0
+    p = np.asarray(y_pred, np.float32).reshape(-1)
+    thr = np.array([0.0 - 1e-7] + [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)] + [1.0 + 1e-7],
+                   np.float32)
+    gt = p[None, :] > thr[:, None]
+    tp = np.sum(gt & y[None, :], axis=1).astype(np.float32)
+    fp = np.sum(gt & ~y[None, :], axis=1).astype(np.float32)
+    P, N = np.float32(np.sum(y)), np.float32(np.sum(~y))
+    tpr = tp / P if P > 0 else np.zeros_like(tp)
+    fpr = fp / N if N > 0 else np.zeros_like(fp)
+    return float(np.sum((fpr[:-1] - fpr[1:]).astype(np.float32) * ((tpr[:-1] + tpr[1:]) * np.float32(0.5))))

@@ -247,6 +247,18 @@ PYBIND11_MODULE(_C, m) {
           "rec_adam_f32");
   });
 
+  m.def("metrics_workspace_bytes", [](int64_t n) { return rec_metrics_workspace_bytes(n); });
+  m.def("binary_crossentropy_f32", [](ptr_t y, ptr_t p, int64_t n, ptr_t out, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_binary_crossentropy_f32(P<const float>(y), P<const float>(p), n, P<float>(out), P<void>(ws),
+                                      P<void>(stream)),
+          "rec_binary_crossentropy_f32");
+  });
+  m.def("auc_f32", [](ptr_t y, ptr_t p, int64_t n, ptr_t out, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_auc_f32(P<const float>(y), P<const float>(p), n, P<float>(out), P<void>(ws), P<void>(stream)),
+          "rec_auc_f32");
+  });
   m.def("topk_ip_f32", [](ptr_t q, int64_t q_stride, int64_t Q, ptr_t items, int64_t items_stride, int64_t N, int d,
                           int k, ptr_t out_scores, ptr_t out_idx, ptr_t stream) {
     py::gil_scoped_release nogil;

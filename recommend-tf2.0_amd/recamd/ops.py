@@ -529,3 +529,28 @@ def topk_inner_product(queries: torch.Tensor, items: torch.Tensor, k: int):
     C.topk_ip_f32(queries.data_ptr(), queries.stride(0), Q, items.data_ptr() if N else 0, items.stride(0) if N else d,
                   N, d, int(k), scores.data_ptr(), idx.data_ptr(), _stream())
     return scores, idx
+
+
+def _metric_args(y_true: torch.Tensor, y_pred: torch.Tensor):
+    y_true = _chk(y_true, "y_true").contiguous().reshape(-1)
+    y_pred = _chk(y_pred, "y_pred").contiguous().reshape(-1)
+    if y_true.numel() != y_pred.numel() or y_true.numel() == 0:
+        raise ValueError("y_true / y_pred must have the same non-zero number of elements")
+    ws = torch.empty(C.metrics_workspace_bytes(y_true.numel()), dtype=torch.uint8, device=y_true.device)
+    out = torch.empty(1, dtype=torch.float32, device=y_true.device)
+    return y_true, y_pred, ws, out
+
+
+def binary_crossentropy(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+    """Mean Keras binary_crossentropy over all samples (probabilities clipped to [1e-7, 1-1e-7]) -> shape (1,)."""
+    y_true, y_pred, ws, out = _metric_args(y_true, y_pred)
+    C.binary_crossentropy_f32(y_true.data_ptr(), y_pred.data_ptr(), y_true.numel(), out.data_ptr(), ws.data_ptr(),
+                              _stream())
+    return out
+
+
+def auc(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+    """tf.keras.metrics.AUC() with its defaults (200 thresholds, ROC, trapezoid) -> shape (1,)."""
+    y_true, y_pred, ws, out = _metric_args(y_true, y_pred)
+    C.auc_f32(y_true.data_ptr(), y_pred.data_ptr(), y_true.numel(), out.data_ptr(), ws.data_ptr(), _stream())
+    return out
