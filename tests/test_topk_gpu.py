@@ -66,3 +66,12 @@ def test_index_flat_ip_object(dev):
     D, I = index.search(np.ascontiguousarray(users), 10)
     eD, eI = ref.topk_inner_product(users, items, 10)
     check(D, I, eD, eI, users, items)
+
+
+def test_empty_index_and_no_queries(dev):
+    from recamd import ops
+    q = torch.randn(3, 8, device=dev)
+    D, I = ops.topk_inner_product(q, torch.empty((0, 8), device=dev), 4)
+    assert torch.isinf(D).all() and (D < 0).all() and (I == -1).all()
+    D, I = ops.topk_inner_product(torch.empty((0, 8), device=dev), torch.randn(5, 8, device=dev), 4)
+    assert D.shape == (0, 4) and I.shape == (0, 4)
