@@ -590,3 +590,15 @@ def keras_auc(y_true, y_pred, num_thresholds=200):
     tpr = tp / P if P > 0 else np.zeros_like(tp)
     fpr = fp / N if N > 0 else np.zeros_like(fp)
     return float(np.sum((fpr[:-1] - fpr[1:]).astype(np.float32) * ((tpr[:-1] + tpr[1:]) * np.float32(0.5))))
+
+
+def match_fm_forward(user_ids, item_ids, user_tables, item_tables, w0, w, V, dtype=np.float64):
+    """src/match/fm/model.py:62-83: stack = [user embeddings, item embeddings]; sigmoid(w0 + stack w +
+    0.5 sum_k((stack V^T)_k^2 - (stack^2 (V^T)^2)_k)).  Returns (out (B,1), user_embeds, item_embeds)."""
+    ue = gather_concat([np.asarray(t, dtype) for t in user_tables], user_ids)
+    ie = gather_concat([np.asarray(t, dtype) for t in item_tables], item_ids)
+    stack = np.concatenate([ue, ie], axis=-1)
+    w0, w, V = (np.asarray(a, dtype) for a in (w0, w, V))
+    first = w0 + stack @ w
+    second = 0.5 * np.sum((stack @ V.T) ** 2 - (stack ** 2) @ (V.T ** 2), axis=1, keepdims=True)
+    return sigmoid(first + second), ue, ie

@@ -161,3 +161,26 @@ def test_ncf(dev, neg):
                           w['neg_item_embedding/embeddings'], layers, (w['dense/kernel'], w['dense/bias']))
     assert out.shape == (B, 1 + neg)
     assert close(out, exp)
+
+
+@pytest.mark.parametrize("D", [8, 6])
+def test_match_fm(dev, D):
+    from match.fm.model import FM
+    rng = np.random.default_rng(40 + D)
+    ucols = match_cols(['user_id', 'gender', 'age'], [300, 3, 8], D)
+    icols = match_cols(['movie_id', 'genre'], [500, 20], D)
+    m = FM(ucols, icols, k=16)
+    B = 203
+    uin = {c['feat']: rng.integers(0, c['feat_num'], size=(B, 1)).astype(np.float32) for c in ucols}
+    iin = {c['feat']: rng.integers(0, c['feat_num'], size=(B, 1)).astype(np.float32) for c in icols}
+    w = randomize(m, rng, 0.2)
+    out = m([uin, iin]).cpu().numpy()
+    uids = np.concatenate([uin[c['feat']] for c in ucols], axis=1)
+    iids = np.concatenate([iin[c['feat']] for c in icols], axis=1)
+    ut = [w[f"user_embed_{c['feat']}/embeddings"] for c in ucols]
+    it = [w[f"item_embed_{c['feat']}/embeddings"] for c in icols]
+    e_out, e_u, e_i = ref.match_fm_forward(uids, iids, ut, it, w['w0'], w['w'], w['V'])
+    assert out.shape == (B, 1)
+    assert close(out, e_out)
+    assert np.array_equal(m.user_embeds.cpu().numpy(), e_u.astype(np.float32))
+    assert np.array_equal(m.item_embeds.cpu().numpy(), e_i.astype(np.float32))
