@@ -284,6 +284,85 @@ __global__ __launch_bounds__(256, WAVES) void pairdot_gram_kernel(
   if (bad && oob_flag) *oob_flag = 1;
 }
 
+// One-shot form (REC_GRAM_CFG=os; 231 us, i.e. slower than the persistent form's 215-226 us: 16 one-sample waves per
+// CU each pay the descriptor -> id -> row dependency chain before their burst starts): one wave per sample, no loop.  The wave resolves its row, issues the sample as one burst, runs
+// the k-steps as the pieces arrive, stages and stores its output row and exits -- stores are the last thing a wave
+// does, so they never sit in front of a load wait, and with no loop-carried state the kernel fits 4 waves per SIMD.
+template <int IDS_F32, int NR, bool HAS_DENSE, bool APPEND>
+__global__ __launch_bounds__(256, 4) void pairdot_gram_oneshot_kernel(
+    TableSet ts, int F, const void* __restrict__ ids, int64_t ids_stride, const float* __restrict__ dense,
+    int64_t dense_stride, int B, float* __restrict__ out, int64_t out_stride, int* __restrict__ oob_flag) {
+  __shared__ __attribute__((aligned(16))) float stage_all[4][640];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
+  float* stage = stage_all[w];
+  const int n = F + (HAS_DENSE ? 1 : 0);
+  const int P = n * (n - 1) / 2;
+  const int W = P + (APPEND ? 128 : 0);
+  const int W4 = (W + 3) >> 2;
+  const int b = blockIdx.x * 4 + w;
+  if (b >= B) return;
+  if (lane < 4) stage[W + lane] = 0.f;
+
+  const bool is_tab = r < F, is_dense = HAS_DENSE && r == F;
+  const int rF = r < F ? r : F - 1;
+  const float* base = ts.base[rF];
+  const uint32_t vocab = is_tab ? (uint32_t)ts.vocab[rF] : 0u;
+  const int32_t id = load_id<IDS_F32>(ids, (int64_t)b * ids_stride + rF);
+  const bool ok = (uint32_t)id < vocab;
+  uintptr_t p = (uintptr_t)g_gram_zero_row;
+  p = is_dense ? (uintptr_t)dense + (uintptr_t)((int64_t)b * dense_stride * 4) : p;
+  p = (is_tab && ok) ? (uintptr_t)base + ((uintptr_t)(uint32_t)id << 9) : p;
+  gp4 pc = (gp4)(p + h * 32);
+  f32x4 x[16];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    x[2 * s] = pc[4 * s];
+    x[2 * s + 1] = pc[4 * s + 1];
+  }
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (APPEND) dv = *(gp4)(uintptr_t)(dense + (int64_t)b * dense_stride + r * 4);
+  __builtin_amdgcn_sched_barrier(0);  // keep the burst whole: hipcc otherwise sinks loads between the MFMAs
+
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    bf16x8 H, M, L;
+    split8(x[2 * s], x[2 * s + 1], H, M, L);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, H, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, M, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(M, H, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(H, L, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(L, H, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(M, M, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = (k & 3) + 8 * (k >> 2) + 4 * h;
+    const int slot = (r < i && i < n) ? i * (i - 1) / 2 + r : 639;
+    stage[slot] = acc[k];
+  }
+  if constexpr (APPEND) {
+    stage[P + 4 * r + 0] = dv.x;
+    stage[P + 4 * r + 1] = dv.y;
+    stage[P + 4 * r + 2] = dv.z;
+    stage[P + 4 * r + 3] = dv.w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  f32x4* orow = reinterpret_cast<f32x4*>(out + (int64_t)b * out_stride);
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    int q = lane + 64 * k;
+    q = q < W4 ? q : W4 - 1;
+    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(stage + 4 * q), orow + q);
+  }
+  if (is_tab && !ok && oob_flag) *oob_flag = 1;
+}
+
 // returns false when the shape is not covered (caller falls through to the VALU kernels)
 bool pairdot128_gram_dispatch(const TableSet& ts, int F, bool has_dense, int ids_f32, const void* ids,
                               int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
@@ -303,6 +382,7 @@ bool pairdot128_gram_dispatch(const TableSet& ts, int F, bool has_dense, int ids
   if (const char* e = getenv("REC_GRAM_CFG")) {  // "<tiles><waves>", A/B measurements only: 13, 22
     if (e[0] == '1' && e[1] == '3') tiles = 1, per_cu = 3;
     if (e[0] == '2' && e[1] == '2') tiles = 2, per_cu = 2;
+    if (e[0] == 'o') tiles = 0;  // one-shot waves
   }
   const int P = n * (n - 1) / 2;
   const bool append = append_dense != 0;
@@ -310,7 +390,7 @@ bool pairdot128_gram_dispatch(const TableSet& ts, int F, bool has_dense, int ids
   const int nr = (W4 + 63) / 64;  // 1..3
   // persistent part: a rectangle of iters x tiles x (4 * grid) samples; remainder: one sample per wave
   const int64_t grid_main = (int64_t)cus * per_cu;
-  const int64_t chunk = grid_main * 4 * tiles;
+  const int64_t chunk = grid_main * 4 * (tiles > 0 ? tiles : 1);
   const int iters = (int)(B / chunk);
   const int B_main = (int)(iters * chunk);
   const int64_t grid_rem = (B - B_main + 3) / 4;
@@ -335,6 +415,29 @@ bool pairdot128_gram_dispatch(const TableSet& ts, int F, bool has_dense, int ids
     else if (!append) REC_GRAM_NR(I_, T_, W_, true, false); \
     else REC_GRAM_NR(I_, T_, W_, true, true);               \
   } while (0)
+  if (tiles == 0) {
+    const int64_t grid = (B + 3) / 4;
+#define REC_GRAM_OS(I_, NR_, HD_, AP_)                                                                             \
+  hipLaunchKernelGGL((pairdot_gram_oneshot_kernel<I_, NR_, HD_, AP_>), dim3((unsigned)grid), dim3(256), 0, st, ts, \
+                     F, ids, ids_stride, dense, dense_stride, (int)B, out, out_stride, oob)
+#define REC_GRAM_OS_NR(I_, HD_, AP_)               \
+  do {                                             \
+    if (nr == 1) REC_GRAM_OS(I_, 1, HD_, AP_);     \
+    else if (nr == 2) REC_GRAM_OS(I_, 2, HD_, AP_); \
+    else REC_GRAM_OS(I_, 3, HD_, AP_);             \
+  } while (0)
+#define REC_GRAM_OS_D(I_)                              \
+  do {                                                 \
+    if (!has_dense) REC_GRAM_OS_NR(I_, false, false);  \
+    else if (!append) REC_GRAM_OS_NR(I_, true, false); \
+    else REC_GRAM_OS_NR(I_, true, true);               \
+  } while (0)
+    if (ids_f32) REC_GRAM_OS_D(1); else REC_GRAM_OS_D(0);
+#undef REC_GRAM_OS_D
+#undef REC_GRAM_OS_NR
+#undef REC_GRAM_OS
+    return true;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     const bool main_part = pass == 0;
     if (main_part ? iters == 0 : grid_rem == 0) continue;

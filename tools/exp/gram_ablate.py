@@ -20,7 +20,7 @@ def t(name):
     b.record(); torch.cuda.synchronize()
     print(f"{name}: {a.elapsed_time(b)/30*1e3:.1f} us", flush=True)
 os.environ["REC_PAIRDOT_IMPL"] = "gram"
-for cfg in ("22", "13"):
+for cfg in ("os", "22"):
     os.environ["REC_GRAM_CFG"] = cfg
     for dbg, nm in ((0, "full"),):
         os.environ["REC_GRAM_DBG"] = str(dbg)
