@@ -1,0 +1,209 @@
+// K11 on the bf16 matrix cores with fp32 accuracy: out = act(x W + b) for the large Dense layers of the towers.
+//
+// fp32 MFMA runs at 256 flop/clk/CU; bf16 MFMA at 4096.  An fp32 value splits EXACTLY into three bf16 terms
+// (x = h + m + l, 8 + 8 + 8 mantissa bits, by truncation; csrc/pairwise_dot_gram.hip uses the same split) and
+// every product of two bf16 values is exact in the fp32 accumulator, so
+//     x W = Xh Wh + (Xh Wm + Xm Wh) + (Xh Wl + Xl Wh) + Xm Wm + O(2^-24 |x||w|)
+// is as accurate as fp32 FMA arithmetic (tests: 1e-5 against the fp64 oracle, like the fp32 kernel) at 6 bf16
+// MFMAs per fp32-equivalent one: 16 / 6 = 2.7x the fp32 matrix-core peak.
+//
+// Workgroup = 128 x 128 output tile, 4 waves (2 x 2, each 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles), K in
+// steps of 16.  Staging: thread (row = tid & 127, kh = tid >> 7) loads 8 consecutive k of one x row and of one W
+// column (the W loads are coalesced across the lanes of a wave: consecutive columns), splits them in registers
+// (~45 VALU ops per operand per k-step, hidden under the 24 MFMAs a wave issues per k-step) and writes one 16-B
+// fragment per plane to LDS laid out [plane][kh][row]: exactly the MFMA operand of lane (row & 31, kh), so the
+// compute phase is 12 conflict-free ds_read_b128 per 24 MFMAs.  LDS is double-buffered, one barrier per k-step.
+#include "common.h"
+
+namespace rec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace b3 {
+constexpr int BM = 128, BN = 128, BK = 16;
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// 8 fp32 -> three bf16x8 fragments with x = h + m + l exactly
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  uint32_t r1[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float hf = bfloat(fbits(x[j]) & 0xffff0000u);
+    const float r = x[j] - hf;
+    const float mf = bfloat(fbits(r) & 0xffff0000u);
+    r1[j] = fbits(r);
+    lo[j] = fbits(r - mf);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    h[t] = pack_top16(fbits(x[2 * t]), fbits(x[2 * t + 1]));
+    m[t] = pack_top16(r1[2 * t], r1[2 * t + 1]);
+    l[t] = pack_top16(lo[2 * t], lo[2 * t + 1]);
+  }
+}
+}  // namespace b3
+
+// XMODE: 1 = aligned x rows (two dwordx4 per thread), 2 = unaligned rows via the borrowed transpose tile,
+// 0 = unaligned rows, scalar loads (short K).  A template parameter: one kernel with all three paths needs 182
+// VGPRs (2 workgroups per CU), the specialised ones 158 (3 per CU), worth 10 %.
+template <int XMODE>
+__global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ alpha, int act, int64_t M,
+                                                              int K, int N, float* __restrict__ out,
+                                                              int64_t out_stride) {
+  using namespace b3;
+  constexpr int x_vec = XMODE;
+  // [stage][operand A/B][plane h/m/l][kh][row] of 16-B fragments: 2*2*3*2*128*16 B = 48 KiB
+  __shared__ u32x4 frag[2][2][3][2][128];
+  // rows of x that are not 16-B aligned (x_stride % 4 != 0, e.g. a tight (M, 479) matrix) cannot be read as two
+  // dwordx4 per thread; they are loaded coalesced along k (lane -> k, 4 rows per wave-instruction) and transposed to
+  // the row-per-thread staging map through an fp32 tile that borrows the B-operand region of the stage being
+  // filled (two extra barriers per k-step on that path only; 48 KiB total keeps 3 workgroups per CU)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int srow = tid & 127, skh = tid >> 7;
+  const int64_t gm = m0 + srow;
+  const int gn = n0 + srow;
+  const bool m_ok = gm < M, n_ok = gn < N;
+  const float* xrow = x + (m_ok ? gm : 0) * x_stride;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float av[8], bv[8];
+  auto gload = [&](int k0) {
+    const int kb = k0 + 8 * skh;
+    if constexpr (x_vec == 2) {
+      const int kk = tid & 15, r0 = tid >> 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t row = m0 + r0 + 16 * j;
+        av[j] = (row < M && k0 + kk < K) ? x[row * x_stride + k0 + kk] : 0.f;
+      }
+    } else if (x_vec == 1 && kb + 8 <= K) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xrow + kb);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(xrow + kb + 4);
+      av[0] = a0.x, av[1] = a0.y, av[2] = a0.z, av[3] = a0.w;
+      av[4] = a1.x, av[5] = a1.y, av[6] = a1.z, av[7] = a1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? xrow[kb + j] : 0.f;
+    }
+    if (x_vec != 2 && !m_ok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (n_ok && kb + j < K) ? W[(int64_t)(kb + j) * N + gn] : 0.f;
+  };
+  auto lwrite = [&](int st) {
+    u32x4 h, m, l;
+    if constexpr (x_vec == 2) {
+      float(*xs)[17] = reinterpret_cast<float(*)[17]>(&frag[st][1][0][0][0]);  // 128 x 17 floats < 12 KiB
+      const int kk = tid & 15, r0 = tid >> 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xs[r0 + 16 * j][kk] = av[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = xs[srow][8 * skh + j];
+    }
+    split8(av, h, m, l);
+    frag[st][0][0][skh][srow] = h;
+    frag[st][0][1][skh][srow] = m;
+    frag[st][0][2][skh][srow] = l;
+    if constexpr (x_vec == 2) __syncthreads();  // the borrowed tile has been read by everyone
+    split8(bv, h, m, l);
+    frag[st][1][0][skh][srow] = h;
+    frag[st][1][1][skh][srow] = m;
+    frag[st][1][2][skh][srow] = l;
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  lwrite(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int st = ks & 1;
+    if (ks + 1 < nk) gload((ks + 1) * BK);
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[t][p] = __builtin_bit_cast(bf16x8, frag[st][0][p][half][wm * 64 + t * 32 + l32]);
+        b[t][p] = __builtin_bit_cast(bf16x8, frag[st][1][p][half][wn * 64 + t * 32 + l32]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // h h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);  // h m
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);  // m h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);  // h l
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);  // l h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // m m
+        acc[i][j] = c;
+      }
+    if (ks + 1 < nk) lwrite(st ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l32;
+      if (col >= N) continue;
+      const float bb = bias ? bias[col] : 0.f;
+      const float al = alpha ? alpha[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][r] + bb, act, al);
+      }
+    }
+}
+
+// caller has validated shapes/pointers (rec_dense_f32)
+bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
+                           int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st) {
+  const int64_t gx = (M + b3::BM - 1) / b3::BM;
+  const int gy = (N + b3::BN - 1) / b3::BN;
+  if (gx > 0x7fffffffLL || gy > 65535) return false;
+  // x staging: 1 = two dwordx4 per thread (aligned rows), 2 = coalesced along k + LDS transpose (unaligned rows,
+  // K large enough to pay for the extra barrier), 0 = scalar loads per thread (unaligned, short K)
+  const int x_vec = (aligned16(x) && x_stride % 4 == 0) ? 1 : (K >= 64 ? 2 : 0);
+  const dim3 grid((unsigned)gx, (unsigned)gy);
+  if (x_vec == 1)
+    hipLaunchKernelGGL(dense_bf16x3_kernel<1>, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, N, out,
+                       out_stride);
+  else if (x_vec == 2)
+    hipLaunchKernelGGL(dense_bf16x3_kernel<2>, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, N, out,
+                       out_stride);
+  else
+    hipLaunchKernelGGL(dense_bf16x3_kernel<0>, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, N, out,
+                       out_stride);
+  return true;
+}
+
+}  // namespace rec

@@ -48,3 +48,42 @@ def test_dense_rank3_and_strided_input(dev):
     W2 = rng.normal(size=(37, 20)).astype(np.float32)
     out2 = ops.dense(tb[:, 3:], torch.from_numpy(W2).to(dev)).cpu().numpy()
     assert close(out2, buf[:, 3:].astype(np.float64) @ W2.astype(np.float64))
+
+
+@pytest.mark.parametrize("M,K,N,aligned", [(2048, 512, 256, True), (1500, 479, 130, False), (1024, 42, 200, False),
+                                           (4096, 64, 128, True)])
+def test_dense_bf16x3_has_fp32_accuracy(dev, monkeypatch, M, K, N, aligned):
+    """The large-layer kernel rebuilds fp32 products from three bf16 terms (csrc/dense_bf16x3.hip): its error against
+    the fp64 oracle must be at the level of the fp32-MFMA kernel's (REC_DENSE_IMPL=f), and the three x staging paths
+    (aligned rows / unaligned rows via the transpose tile / short-K scalar loads) must agree with the oracle."""
+    from recamd import ops
+    rng = np.random.default_rng(K)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    W = (rng.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    tx = t(x)
+    assert (tx.stride(0) % 4 == 0) == aligned
+    exp = ref.dense(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64), "relu")
+    monkeypatch.setenv("REC_DENSE_IMPL", "b")
+    got_b = ops.dense(tx, t(W), t(b), "relu").cpu().numpy()
+    monkeypatch.setenv("REC_DENSE_IMPL", "f")
+    got_f = ops.dense(tx, t(W), t(b), "relu").cpu().numpy()
+    err_b, err_f = np.abs(got_b - exp).max(), np.abs(got_f - exp).max()
+    assert close(got_b, exp)
+    assert err_b <= 2.0 * err_f + 1e-7, (err_b, err_f)
+
+
+def test_dense_bf16x3_tiny_and_mixed_magnitudes(dev, monkeypatch):
+    """values spanning 2^-20 .. 2^10 in one row: the hi/mid/lo split is exact per element, so small terms
+    next to large ones keep their fp32 contribution"""
+    from recamd import ops
+    monkeypatch.setenv("REC_DENSE_IMPL", "b")
+    rng = np.random.default_rng(1)
+    M, K, N = 1024, 128, 96
+    x = (rng.normal(size=(M, K)) * np.exp2(rng.integers(-20, 11, size=(M, K)))).astype(np.float32)
+    W = (rng.normal(size=(K, N)) * np.exp2(rng.integers(-10, 3, size=(K, N)))).astype(np.float32)
+    got = ops.dense(torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev)).cpu().numpy()
+    exp = x.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(x.astype(np.float64)) @ np.abs(W.astype(np.float64))
+    assert np.all(np.abs(got - exp) <= 2e-6 * scale + 1e-30)   # a-priori fp32 bound is K * 2^-24 = 7.6e-6

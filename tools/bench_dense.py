@@ -10,14 +10,16 @@ def t(fn, it=20):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
-for (M, K, N) in [(1638400, 64, 64), (1638400, 64, 128), (1638400, 128, 64), (65536, 128, 64), (65536, 13, 512), (65536, 512, 256), (65536, 479, 1024), (65536, 1024, 512)]:
+for (M, K, N) in [(1638400, 64, 64), (1638400, 64, 128), (1638400, 128, 64), (65536, 128, 64), (65536, 13, 512), (65536, 512, 256), (65536, 479, 1024), (65536, 1024, 512), (65536, 3456, 128), (65536, 3341, 256), (8192, 4096, 4096)]:
     x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev); b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
     ms = t(lambda: ops.dense(x, W, b, "relu", out=out))
     os.environ["REC_DENSE_IMPL"] = "t"
     ms_t = t(lambda: ops.dense(x, W, b, "relu", out=out))
+    os.environ["REC_DENSE_IMPL"] = "b"
+    ms_b = t(lambda: ops.dense(x, W, b, "relu", out=out))
     del os.environ["REC_DENSE_IMPL"]
     ms_torch = t(lambda: torch.relu(torch.addmm(b, x, W)))
     fl = 2.0 * M * K * N
     by = 4.0 * (M * K + M * N + K * N)
-    print(f"M={M} K={K} N={N}: ours {ms:.3f} ms ({fl/ms/1e9:.1f} TF, {by/ms/1e6:.0f} GB/s) tiled {ms_t:.3f} ms torch {ms_torch:.3f} ms")
+    print(f"M={M} K={K} N={N}: ours {ms:.3f} ms ({fl/ms/1e9:.1f} TF, {by/ms/1e6:.0f} GB/s) fp32-MFMA tiled {ms_t:.3f} ms  bf16x3 {ms_b:.3f} ms ({fl/ms_b/1e9:.1f} TF)  torch {ms_torch:.3f} ms")
