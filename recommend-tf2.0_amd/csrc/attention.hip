@@ -315,6 +315,8 @@ __global__ __launch_bounds__(256) void mha_rowmask_kernel(const float* __restric
   for (int c = 0; c < DK / 4; ++c) reinterpret_cast<f32x4*>(orow)[c] = acc[c] * inv;
 }
 
+bool mha_rowmask_b3_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B, int Sq,
+                             int Sk, int dk, int H, float* out, hipStream_t st);
 bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
                                int Sq, int Sk, int dk, int H, float* out, hipStream_t st);
 bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
@@ -434,9 +436,19 @@ extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* 
   REC_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), REC_EINVAL,
                 "%s: q/k/v/out must be 16-B aligned", who);
   REC_CHECK_ARG(B <= 65535, REC_ESHAPE, "%s: B > 65535 per call (chunk the batch)", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    // default for Sq > 8, dk in {32, 64}: bf16x3 matrix-core kernel streaming K/V tiles (attention_b3.hip; no
+    // sequence-length limit).  REC_MHA_IMPL = "f32" keeps the fp32-MFMA kernel, "valu" the round-1 VALU kernel.
+    const char* e = getenv("REC_MHA_IMPL");
+    if (!(e && (e[0] == 'v' || e[0] == 'f')) && Sq > 8 &&
+        mha_rowmask_b3_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, st)) {
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
+  }
   const size_t lds = (size_t)2 * Sk * dk * sizeof(float);
   REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: Sk=%d dk=%d needs %zu B of LDS", who, Sk, dk, lds);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     const char* e = getenv("REC_MHA_IMPL");  // "valu" forces the round-1 VALU kernel (A/B only)
     if (!(e && e[0] == 'v') && mha_rowmask_mfma_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, st)) {
