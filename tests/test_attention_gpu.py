@@ -118,7 +118,9 @@ def test_din_attention_pool_distinct_v(dev):
 @pytest.mark.parametrize("B,Sq,Sk,dm,H", [(1, 1, 1, 8, 1), (8, 200, 200, 64, 1), (3, 10, 10, 64, 2), (5, 300, 300, 64, 4),
                                           (6, 1, 200, 64, 1), (2, 33, 33, 128, 2),
                                           (4, 3, 50, 64, 2), (7, 8, 33, 64, 4), (5, 2, 200, 128, 2),   # decode-style kernel
-                                          (3, 64, 64, 64, 2), (2, 100, 40, 64, 1), (2, 17, 257, 32, 1)])  # MFMA kernel
+                                          (3, 64, 64, 64, 2), (2, 100, 40, 64, 1), (2, 17, 257, 32, 1),   # MFMA kernel
+                                          (2, 600, 700, 128, 2), (1, 40, 1500, 32, 1),   # longer than the fp32 kernel's LDS
+                                          (2, 290, 31, 64, 2), (3, 16, 32, 64, 1)])        # > 8 query tiles, 1 key tile
 def test_mha_rowmask(dev, B, Sq, Sk, dm, H):
     from recamd import ops
     rng = np.random.default_rng(B + Sq + dm + H)
