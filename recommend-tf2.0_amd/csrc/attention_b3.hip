@@ -13,6 +13,8 @@
 //
 // Every fp32 operand (Q, K, V and the probabilities) is split exactly into three bf16 terms and each product is
 // rebuilt from six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl, lh, mm): fp32 accuracy at 2.7x the fp32 MFMA peak.
+// (Tried: 4-wave workgroups per group of 4 query tiles so that two share a CU: 0.83 ms against 0.79 ms at config 5 --
+// the second pass over K/V and its splits cost more than the overlap wins.)
 // Staging per key tile: K rows split and written as MFMA fragments [plane][k-step][half][key]; V rows go to an fp32
 // scratch tile first and are read back transposed (8 keys of one feature column) before the split.
 #include <math.h>
