@@ -164,6 +164,198 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 3 : 2)) void topk_ip_kernel(const f
   }
 }
 
+
+// ---- the same kernel on the bf16 matrix cores with fp32 accuracy (exact 3-term bf16 split, see dense_bf16x3.hip):
+// scores = Qh Ih + Qh Im + Qm Ih + Qh Il + Ql Ih + Qm Im.  The query fragments of a wave's 32 rows are loaded
+// straight from global memory in MFMA operand layout and stay in registers; an item tile is staged whole (all
+// k-steps, three planes) as [k-step][plane][half][row] fragments, prefetched in registers one tile ahead.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+namespace tb3 {
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  uint32_t r1[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float hf = bfloat(fbits(x[j]) & 0xffff0000u);
+    const float r = x[j] - hf;
+    const float mf = bfloat(fbits(r) & 0xffff0000u);
+    r1[j] = fbits(r);
+    lo[j] = fbits(r - mf);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    h[t] = pack_top16(fbits(x[2 * t]), fbits(x[2 * t + 1]));
+    m[t] = pack_top16(r1[2 * t], r1[2 * t + 1]);
+    l[t] = pack_top16(lo[2 * t], lo[2 * t + 1]);
+  }
+}
+}  // namespace tb3
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restrict__ q, int64_t q_stride,
+                                                            const float* __restrict__ items, int64_t items_stride,
+                                                            int64_t Q, int N, int d, int k,
+                                                            float* __restrict__ out_scores,
+                                                            int64_t* __restrict__ out_idx, int vec_ok) {
+  using namespace topk;
+  using namespace tb3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* Bf = reinterpret_cast<u32x4*>(smem_raw);                       // [KS][3][2][128]
+  float* run_s = reinterpret_cast<float*>(Bf + KS * 3 * 2 * 128);       // [BM][KMAX]
+  int* run_i = reinterpret_cast<int*>(run_s + BM * KMAX);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+  for (int e = tid; e < BM * KMAX; e += 256) {
+    run_s[e] = -INFINITY;
+    run_i[e] = -1;
+  }
+
+  auto load8 = [&](const float* base, int64_t stride, int64_t row, bool row_ok, int kb, float (&r)[8]) {
+    const float* p = base + (row_ok ? row : 0) * stride + kb;
+    if (vec_ok && row_ok && kb + 8 <= d) {
+      const f32x4t a0 = *reinterpret_cast<const f32x4t*>(p), a1 = *reinterpret_cast<const f32x4t*>(p + 4);
+      r[0] = a0.x, r[1] = a0.y, r[2] = a0.z, r[3] = a0.w;
+      r[4] = a1.x, r[5] = a1.y, r[6] = a1.z, r[7] = a1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (row_ok && kb + j < d) ? p[j] : 0.f;
+    }
+  };
+
+  // A operand: lane (row l32 of the wave's 32 queries, k-half) for every k-step
+  u32x4 qf[KS][3];
+  {
+    const int64_t gm = m0 + wv * 32 + l32;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float x[8];
+      load8(q, q_stride, gm, gm < Q, ks * BK + 8 * half, x);
+      split8(x, qf[ks][0], qf[ks][1], qf[ks][2]);
+    }
+  }
+
+  // item staging: thread (row = tid & 127, k-half = tid >> 7), all k-steps of the tile, one tile ahead
+  const int srow = tid & 127, skh = tid >> 7;
+  float bv[KS][8];
+  auto gload = [&](int n0) {
+    const int64_t gn = (int64_t)n0 + srow;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) load8(items, items_stride, gn, gn < N, ks * BK + 8 * skh, bv[ks]);
+  };
+  auto lwrite = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 h, m, l;
+      split8(bv[ks], h, m, l);
+      Bf[((ks * 3 + 0) * 2 + skh) * 128 + srow] = h;
+      Bf[((ks * 3 + 1) * 2 + skh) * 128 + srow] = m;
+      Bf[((ks * 3 + 2) * 2 + skh) * 128 + srow] = l;
+    }
+  };
+  if (N > 0) gload(0);
+  __syncthreads();
+
+  for (int n0 = 0; n0 < N; n0 += BN) {
+    lwrite();
+    __syncthreads();
+    if (n0 + BN < N) gload(n0 + BN);
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, qf[ks][0]), am = __builtin_bit_cast(bf16x8, qf[ks][1]),
+                   al = __builtin_bit_cast(bf16x8, qf[ks][2]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, Bf[((ks * 3 + 0) * 2 + half) * 128 + j * 32 + l32]);
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, Bf[((ks * 3 + 1) * 2 + half) * 128 + j * 32 + l32]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, Bf[((ks * 3 + 2) * 2 + half) * 128 + j * 32 + l32]);
+        f32x16 c = acc[j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        acc[j] = c;
+      }
+    }
+    __syncthreads();  // every wave has read the fragments; the next lwrite may overwrite them
+
+    // top-k update in registers: accumulator register r of half-wave `half` is query row
+    // wv*32 + (r&3) + 8*(r>>2) + 4*half, item columns n0 + 32 j + l32 (j = 0..3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool live = m0 + row < Q;
+      float v[5];
+      int id[5];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = n0 + 32 * j + l32;
+        v[j] = (live && c < N) ? acc[j][r] : -INFINITY;
+        id[j] = (live && c < N) ? c : -1;
+      }
+      const float thr = run_s[row * KMAX + k - 1];
+      const int thr_i = run_i[row * KMAX + k - 1];
+      const bool cand = better(v[0], id[0], thr, thr_i) || better(v[1], id[1], thr, thr_i) ||
+                        better(v[2], id[2], thr, thr_i) || better(v[3], id[3], thr, thr_i);
+      if (!__any(cand)) continue;  // wave-uniform: neither of the two rows of this register has a candidate
+      v[4] = l32 < k ? run_s[row * KMAX + l32] : -INFINITY;
+      id[4] = l32 < k ? run_i[row * KMAX + l32] : -1;
+      float my_s = -INFINITY;
+      int my_i = -1;
+      for (int t = 0; t < k; ++t) {
+        float bs = v[0];
+        int bi = id[0];
+#pragma unroll
+        for (int j = 1; j < 5; ++j)
+          if (better(v[j], id[j], bs, bi)) bs = v[j], bi = id[j];
+        float ws = bs;
+        int wi = bi;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {  // stays inside the 32-lane half
+          const float os = __shfl_xor(ws, off);
+          const int oi = __shfl_xor(wi, off);
+          if (better(os, oi, ws, wi)) ws = os, wi = oi;
+        }
+        if (l32 == t) my_s = ws, my_i = wi;
+        if (wi >= 0 && wi == bi) {  // the owner retires the slot (indices are unique within a row)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (id[j] == wi) v[j] = -INFINITY, id[j] = -1;
+        }
+      }
+      if (l32 < k) {
+        run_s[row * KMAX + l32] = my_s;
+        run_i[row * KMAX + l32] = my_i;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int e = tid; e < BM * k; e += 256) {
+    const int row = e / k, t = e - row * k;
+    if (m0 + row < Q) {
+      out_scores[(m0 + row) * k + t] = run_s[row * KMAX + t];
+      out_idx[(m0 + row) * k + t] = (int64_t)run_i[row * KMAX + t];
+    }
+  }
+}
+
 }  // namespace rec
 
 using namespace rec;
@@ -181,6 +373,27 @@ extern "C" int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q
   const int64_t blocks = (Q + topk::BM - 1) / topk::BM;
   REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "%s: too many queries", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    const char* e = getenv("REC_TOPK_IMPL");  // "f32": fp32-MFMA kernel (A/B only)
+    if (!(e && e[0] == 'f') && d <= 64) {  // d > 64: the bf16x3 form would spill (96 query + 64 staging VGPRs)
+      const int vec_ok = (aligned16(queries) && aligned16(items) && q_stride % 4 == 0 && items_stride % 4 == 0) ? 1 : 0;
+#define REC_TOPK_B3(KS_)                                                                                          \
+  do {                                                                                                            \
+    const size_t lds = (size_t)KS_ * 3 * 2 * 128 * 16 + (size_t)topk::BM * topk::KMAX * 8;                        \
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_ip_b3_kernel<KS_>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+    REC_CHECK_ARG(he == hipSuccess, REC_EHIP, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(he));         \
+    hipLaunchKernelGGL((topk_ip_b3_kernel<KS_>), dim3((unsigned)blocks), dim3(256), lds, st, queries, q_stride,   \
+                       items, items_stride, Q, (int)N, d, k, out_scores, out_idx, vec_ok);                        \
+  } while (0)
+      if (d <= 16) REC_TOPK_B3(1);
+      else if (d <= 32) REC_TOPK_B3(2);
+      else REC_TOPK_B3(4);
+#undef REC_TOPK_B3
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
+  }
 #define REC_TOPK(KS_)                                                                                           \
   hipLaunchKernelGGL((topk_ip_kernel<KS_>), dim3((unsigned)blocks), dim3(256), 0, st, queries, q_stride, items, \
                      items_stride, Q, (int)N, d, k, out_scores, out_idx)
