@@ -275,7 +275,10 @@ static void launch_skinny(const float* x, int64_t x_stride, const float* W, cons
 bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
                            int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st);
 
-// REC_DENSE_IMPL: 't' = fp32-MFMA tiled kernel for everything, 'f' = fp32 MFMA instead of the bf16x3 kernel,
+bool dense_b3_rows_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
+                            int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st);
+
+// REC_DENSE_IMPL: 's' = keep the fp32-MFMA skinny kernels (instead of the bf16x3 row-streaming form), 't' = fp32-MFMA tiled kernel for everything, 'f' = fp32 MFMA instead of the bf16x3 kernel,
 // 'b' = bf16x3 kernel wherever it is applicable (A/B measurements)
 static char dense_impl() {
   const char* e = getenv("REC_DENSE_IMPL");
@@ -300,6 +303,13 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
   // N in (64, 128] with M >= 1024 goes to the bf16x3 kernel below (0.37 ms vs 0.56 ms at 1.6 M x 64 x 128)
   const bool skinny = N > 8 && N <= 128 && (N <= 64 || ((N - 64) % 4 == 0 && M < 1024)) && (K == 16 || K == 32 || K == 64 || K == 128) && M >= 256 && aligned16(x) &&
                       x_stride % 4 == 0 && dense_impl() != 't' && dense_impl() != 'b';
+  // the smallest layers (K, N <= 64), many rows: bf16x3 row-streaming kernel (0.277 ms vs 0.300 ms at 1.6 M x 64 x 64;
+  // it loses beyond that: 0.55 vs 0.37 ms at N = 128, 0.63 vs 0.43 ms at K = 128)
+  if (N > 8 && K <= 64 && N <= 64 && M >= 1024 && dense_impl() != 't' && dense_impl() != 's' && dense_impl() != 'f' &&
+      dense_b3_rows_dispatch(x, x_stride, W, bias, alpha, act, M, K, N, out, out_stride, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (skinny) {
     // N in (64, 128]: two column halves (x is read twice, still ahead of the tiled kernel at these widths)
     for (int n0 = 0; n0 < N; n0 += 64) {

@@ -207,3 +207,172 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
 }
 
 }  // namespace rec
+
+// ------------------------------------------------------------------------------------------------------------
+// Row-streaming form for the zoo's skinny layers (K <= 128, N <= 128: attention projections, FFN, tower heads),
+// which are HBM-bound (x in, out back, W tiny).  W is split once per workgroup into B-operand fragments resident in
+// LDS; persistent waves stream 32-row tiles of x: a lane (row, k-half) loads its own row's 8-float pieces straight
+// from global memory in MFMA operand layout (no LDS hop for x), one tile prefetched in registers; the 32 x N result
+// is transposed through a wave-private LDS tile so that it leaves as 16-B row-major stores.
+// ------------------------------------------------------------------------------------------------------------
+namespace rec {
+
+template <int KS, int NT>
+__global__ __launch_bounds__(256, 3) void dense_b3_rows_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ alpha, int act, int64_t M,
+                                                               int K, int N, float* __restrict__ out,
+                                                               int64_t out_stride, int out_vec) {
+  using namespace b3;
+  constexpr int NC = 32 * NT;       // padded columns
+  constexpr int LDO = NC + 4;       // output staging row stride (floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned char b3r_smem[];
+  u32x4(*Wf)[3][2][NC] = reinterpret_cast<u32x4(*)[3][2][NC]>(b3r_smem);                      // [KS][3][2][NC]
+  float* ost = reinterpret_cast<float*>(b3r_smem + (size_t)KS * 3 * 2 * NC * sizeof(u32x4));  // [4][32 * LDO]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+
+  // W fragments: (ks, half, col) -> 8 consecutive k of one column
+  for (int e = tid; e < KS * 2 * NC; e += 256) {
+    const int col = e % NC, kh = (e / NC) & 1, ks = e / (2 * NC);
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = ks * 16 + kh * 8 + j;
+      w[j] = (col < N && kk < K) ? W[(int64_t)kk * N + col] : 0.f;
+    }
+    u32x4 h, m, l;
+    split8(w, h, m, l);
+    Wf[ks][0][kh][col] = h;
+    Wf[ks][1][kh][col] = m;
+    Wf[ks][2][kh][col] = l;
+  }
+  float bcol[NT], acol[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 32 + l32;
+    bcol[t] = (bias && col < N) ? bias[col] : 0.f;
+    acol[t] = (alpha && col < N) ? alpha[col] : 0.f;
+  }
+  __syncthreads();
+
+  const int64_t ntiles = (M + 31) / 32;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t rt = (int64_t)blockIdx.x * 4 + wv;
+  f32x4 xa[KS][2];
+  auto gload = [&](int64_t tile) {
+    const int64_t row = tile * 32 + l32;
+    const bool ok = tile < ntiles && row < M;
+    const float* p = x + (ok ? row : 0) * x_stride + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ok && ks * 16 + 8 * half + 8 <= K) {
+        xa[ks][0] = *reinterpret_cast<const f32x4*>(p + 16 * ks);
+        xa[ks][1] = *reinterpret_cast<const f32x4*>(p + 16 * ks + 4);
+      } else {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (ok && ks * 16 + 8 * half + j < K) ? p[16 * ks + j] : 0.f;
+        xa[ks][0] = f32x4{t[0], t[1], t[2], t[3]};
+        xa[ks][1] = f32x4{t[4], t[5], t[6], t[7]};
+      }
+    }
+  };
+  if (rt < ntiles) gload(rt);
+  float* st = ost + wv * 32 * LDO;
+  for (; rt < ntiles; rt += nwaves) {
+    u32x4 af[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float t[8] = {xa[ks][0].x, xa[ks][0].y, xa[ks][0].z, xa[ks][0].w,
+                          xa[ks][1].x, xa[ks][1].y, xa[ks][1].z, xa[ks][1].w};
+      split8(t, af[ks][0], af[ks][1], af[ks][2]);
+    }
+    gload(rt + nwaves);  // prefetch the wave's next tile (zeros past the end)
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, af[ks][0]), am = __builtin_bit_cast(bf16x8, af[ks][1]),
+                   al = __builtin_bit_cast(bf16x8, af[ks][2]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, Wf[ks][0][half][t * 32 + l32]);
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, Wf[ks][1][half][t * 32 + l32]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, Wf[ks][2][half][t * 32 + l32]);
+        f32x16 c = acc[t];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        acc[t] = c;
+      }
+    }
+    // bias + activation, then transpose through the wave's LDS tile: C[row = (r&3)+8(r>>2)+4 half][col = l32]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        st[row * LDO + t * 32 + l32] = act_apply(acc[t][r] + bcol[t], act, acol[t]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t row0 = rt * 32;
+    if (out_vec) {  // N % 4 == 0, 16-B aligned rows
+      const int n4 = N >> 2;
+      for (int e = lane; e < 32 * n4; e += 64) {
+        const int row = e / n4, c4 = e - row * n4;
+        if (row0 + row < M)
+          *reinterpret_cast<f32x4*>(out + (row0 + row) * out_stride + 4 * c4) =
+              *reinterpret_cast<const f32x4*>(st + row * LDO + 4 * c4);
+      }
+    } else {
+      for (int e = lane; e < 32 * N; e += 64) {
+        const int row = e / N, c = e - row * N;
+        if (row0 + row < M) out[(row0 + row) * out_stride + c] = st[row * LDO + c];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// returns false when the shape is not covered
+bool dense_b3_rows_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
+                            int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st) {
+  if (K > 128 || N > 128 || !aligned16(x) || x_stride % 4 != 0) return false;
+  const int ks = (K + 15) / 16, nt = (N + 31) / 32;
+  if (ks * nt > 16) return false;  // W fragments: ks * nt * 3 KiB of LDS
+  const int out_vec = (aligned16(out) && out_stride % 4 == 0 && N % 4 == 0) ? 1 : 0;
+  const int64_t ntiles = (M + 31) / 32;
+  int64_t blocks = (ntiles + 3) / 4;
+  if (blocks > 256 * 3) blocks = 256 * 3;
+  bool done = false;
+#define REC_B3R(KS_, NT_)                                                                                         \
+  if (!done && ks <= KS_ && nt == NT_) {                                                                          \
+    const size_t lds = (size_t)KS_ * 3 * 2 * (32 * NT_) * 16 + (size_t)4 * 32 * (32 * NT_ + 4) * sizeof(float);   \
+    if (lds > 64 * 1024 &&                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dense_b3_rows_kernel<KS_, NT_>),                        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                  \
+      return false;                                                                                               \
+    hipLaunchKernelGGL((dense_b3_rows_kernel<KS_, NT_>), dim3((unsigned)blocks), dim3(256), lds, st, x, x_stride, \
+                       W, bias, alpha, act, M, K, N, out, out_stride, out_vec);                                   \
+    done = true;                                                                                                  \
+  }
+  REC_B3R(1, 1) REC_B3R(2, 1) REC_B3R(4, 1)
+  REC_B3R(1, 2) REC_B3R(2, 2) REC_B3R(4, 2) REC_B3R(8, 2)
+  REC_B3R(1, 3) REC_B3R(2, 3) REC_B3R(4, 3)
+  REC_B3R(1, 4) REC_B3R(2, 4) REC_B3R(4, 4)
+#undef REC_B3R
+  return done;
+}
+
+}  // namespace rec
