@@ -145,6 +145,17 @@ int rec_dense_f32(const float* x, int64_t x_stride, const float* W, const float*
                   const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
                   float* out, int64_t out_stride, void* stream);
 
+/* Prepared weights for the large-layer path: the bf16x3 kernel splits every fp32 operand into three bf16 planes;
+ * for W (constant between optimiser steps) that split can be done once.  `prepared` is an opaque device buffer of
+ * rec_dense_prepared_bytes(K, N) bytes filled by rec_dense_prepare_f32; rec_dense_prep_f32 is rec_dense_f32 with
+ * that buffer as a hint (NULL allowed; results are identical either way, layers routed to other kernels ignore
+ * it).  Re-prepare whenever W changes. */
+int64_t rec_dense_prepared_bytes(int32_t K, int32_t N);
+int rec_dense_prepare_f32(const float* W, int32_t K, int32_t N, void* prepared, void* stream);
+int rec_dense_prep_f32(const float* x, int64_t x_stride, const float* W, const void* prepared,
+                       const float* bias, const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
+                       float* out, int64_t out_stride, void* stream);
+
 /* ---- a7 / K6: ctr MultiHeadAttention (AutoInt interacting layer) ----------------------------
  * src/ctr/layers/modules.py:285-325.  q = act(Xq Wq), k = act(Xk Wk), v = act(Xv Wv) (no bias),
  * heads (B,H,N,S); P = softmax(q k^T * sqrt(S)) (the reference DIVIDES by S^-0.5, :235-237);

@@ -272,8 +272,11 @@ static void launch_skinny(const float* x, int64_t x_stride, const float* W, cons
                      bias, alpha, act, M, K, N, w_stride, out, out_stride);
 }
 
-bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
-                           int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st);
+bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, const void* Wp, const float* bias,
+                           const float* alpha, int act, int64_t M, int K, int N, float* out, int64_t out_stride,
+                           hipStream_t st);
+int64_t dense_prepared_bytes(int K, int N);
+void dense_prepare_launch(const float* W, int K, int N, void* Wp, hipStream_t st);
 
 bool dense_b3_rows_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
                             int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st);
@@ -289,10 +292,9 @@ static char dense_impl() {
 
 using namespace rec;
 
-extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, const float* bias,
-                             const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
-                             float* out, int64_t out_stride, void* stream) {
-  const char* who = "rec_dense_f32";
+static int dense_impl_f32(const char* who, const float* x, int64_t x_stride, const float* W, const void* prepared,
+                          const float* bias, const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
+                          float* out, int64_t out_stride, void* stream) {
   REC_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && x_stride >= K && out_stride >= N, REC_ESHAPE,
                 "%s: bad shape M=%lld K=%d N=%d", who, (long long)M, K, N);
   REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_PRELU, REC_EINVAL, "%s: bad act %d", who, act);
@@ -334,7 +336,7 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
   // large layers: bf16x3 on the bf16 matrix cores (fp32-accurate, 2.7x the fp32 MFMA peak)
   const bool big = N > 8 && (dense_impl() == 'b' || (M >= 1024 && (int64_t)K * N >= 64 * 64));
   if (big && dense_impl() != 't' && dense_impl() != 'f' &&
-      dense_bf16x3_dispatch(x, x_stride, W, bias, alpha, act, M, K, N, out, out_stride, st)) {
+      dense_bf16x3_dispatch(x, x_stride, W, prepared, bias, alpha, act, M, K, N, out, out_stride, st)) {
     REC_CHECK_LAUNCH(who);
     return REC_OK;
   }
@@ -351,4 +353,32 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
   }
   REC_CHECK_LAUNCH(who);
   return REC_OK;
+}
+
+extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, const float* bias,
+                             const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
+                             float* out, int64_t out_stride, void* stream) {
+  return dense_impl_f32("rec_dense_f32", x, x_stride, W, nullptr, bias, alpha, act, M, K, N, out, out_stride, stream);
+}
+
+extern "C" int64_t rec_dense_prepared_bytes(int32_t K, int32_t N) {
+  if (K < 1 || N < 1) return 0;
+  return dense_prepared_bytes(K, N);
+}
+
+extern "C" int rec_dense_prepare_f32(const float* W, int32_t K, int32_t N, void* prepared, void* stream) {
+  const char* who = "rec_dense_prepare_f32";
+  REC_CHECK_ARG(K >= 1 && N >= 1, REC_ESHAPE, "%s: K=%d N=%d", who, K, N);
+  REC_CHECK_ARG(W && prepared && aligned16(prepared), REC_EINVAL, "%s: NULL or unaligned pointer", who);
+  dense_prepare_launch(W, K, N, prepared, reinterpret_cast<hipStream_t>(stream));
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_dense_prep_f32(const float* x, int64_t x_stride, const float* W, const void* prepared,
+                                  const float* bias, const float* alpha, int32_t act, int64_t M, int32_t K,
+                                  int32_t N, float* out, int64_t out_stride, void* stream) {
+  REC_CHECK_ARG(!prepared || aligned16(prepared), REC_EINVAL, "rec_dense_prep_f32: prepared not 16-B aligned");
+  return dense_impl_f32("rec_dense_prep_f32", x, x_stride, W, prepared, bias, alpha, act, M, K, N, out, out_stride,
+                        stream);
 }

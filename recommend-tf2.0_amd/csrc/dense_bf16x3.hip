@@ -55,13 +55,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, 
 // XMODE: 1 = aligned x rows (two dwordx4 per thread), 2 = unaligned rows via the borrowed transpose tile,
 // 0 = unaligned rows, scalar loads (short K).  A template parameter: one kernel with all three paths needs 182
 // VGPRs (2 workgroups per CU), the specialised ones 158 (3 per CU), worth 10 %.
-template <int XMODE>
+template <int XMODE, bool BPREP>
 __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __restrict__ x, int64_t x_stride,
                                                               const float* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ alpha, int act, int64_t M,
                                                               int K, int N, float* __restrict__ out,
-                                                              int64_t out_stride, int out_vec) {
+                                                              int64_t out_stride, int out_vec, const u32x4* __restrict__ Wp, int Np) {
   using namespace b3;
   constexpr int x_vec = XMODE;
   // [stage][operand A/B][plane h/m/l][kh][row] of 16-B fragments: 2*2*3*2*128*16 B = 48 KiB
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float av[8], bv[8];
+  u32x4 bq[3];
   auto gload = [&](int k0) {
     const int kb = k0 + 8 * skh;
     if constexpr (x_vec == 2) {
@@ -112,8 +113,15 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = 0.f;
     }
+    if constexpr (BPREP) {
+      // prepared weights: [k / 8][plane][Np] fragments, already split (rec_dense_prepare_f32); padded with zeros
+      const int64_t k8 = (k0 >> 3) + skh;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = (n_ok && kb + j < K) ? W[(int64_t)(kb + j) * N + gn] : 0.f;
+      for (int p = 0; p < 3; ++p) bq[p] = Wp[(k8 * 3 + p) * Np + n0 + srow];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = (n_ok && kb + j < K) ? W[(int64_t)(kb + j) * N + gn] : 0.f;
+    }
   };
   auto lwrite = [&](int st) {
     u32x4 h, m, l;
@@ -131,10 +139,16 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
     frag[st][0][1][skh][srow] = m;
     frag[st][0][2][skh][srow] = l;
     if constexpr (x_vec == 2) __syncthreads();  // the borrowed tile has been read by everyone
-    split8(bv, h, m, l);
-    frag[st][1][0][skh][srow] = h;
-    frag[st][1][1][skh][srow] = m;
-    frag[st][1][2][skh][srow] = l;
+    if constexpr (BPREP) {
+      frag[st][1][0][skh][srow] = bq[0];
+      frag[st][1][1][skh][srow] = bq[1];
+      frag[st][1][2][skh][srow] = bq[2];
+    } else {
+      split8(bv, h, m, l);
+      frag[st][1][0][skh][srow] = h;
+      frag[st][1][1][skh][srow] = m;
+      frag[st][1][2][skh][srow] = l;
+    }
   };
 
   const int nk = (K + BK - 1) / BK;
@@ -218,9 +232,30 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
     }
 }
 
-// caller has validated shapes/pointers (rec_dense_f32)
-bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
-                           int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st) {
+// W -> [ceil(K/16)*2][3 planes][Np = round_up(N, 128)] bf16x8 fragments (8 consecutive k of one column each)
+__global__ __launch_bounds__(256) void dense_prepare_kernel(const float* __restrict__ W, int K, int N, int Np, int K8,
+                                                            u32x4* __restrict__ Wp) {
+  using namespace b3;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)K8 * Np) return;
+  const int k8 = (int)(e / Np), n = (int)(e - (int64_t)k8 * Np);
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kk = k8 * 8 + j;
+    w[j] = (n < N && kk < K) ? W[(int64_t)kk * N + n] : 0.f;
+  }
+  u32x4 h, m, l;
+  split8(w, h, m, l);
+  Wp[((int64_t)k8 * 3 + 0) * Np + n] = h;
+  Wp[((int64_t)k8 * 3 + 1) * Np + n] = m;
+  Wp[((int64_t)k8 * 3 + 2) * Np + n] = l;
+}
+
+// caller has validated shapes/pointers (rec_dense_f32 / rec_dense_prep_f32); Wp may be NULL
+bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, const void* Wp, const float* bias,
+                           const float* alpha, int act, int64_t M, int K, int N, float* out, int64_t out_stride,
+                           hipStream_t st) {
   const int64_t gx = (M + b3::BM - 1) / b3::BM;
   const int gy = (N + b3::BN - 1) / b3::BN;
   if (gx > 0x7fffffffLL || gy > 65535) return false;
@@ -229,16 +264,33 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
   const int x_vec = (aligned16(x) && x_stride % 4 == 0) ? 1 : (K >= 64 ? 2 : 0);
   const dim3 grid((unsigned)gx, (unsigned)gy);
   const int out_vec = (aligned16(out) && out_stride % 4 == 0 && N % 4 == 0) ? 1 : 0;
-  if (x_vec == 1)
-    hipLaunchKernelGGL(dense_bf16x3_kernel<1>, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, N, out,
-                       out_stride, out_vec);
-  else if (x_vec == 2)
-    hipLaunchKernelGGL(dense_bf16x3_kernel<2>, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, N, out,
-                       out_stride, out_vec);
-  else
-    hipLaunchKernelGGL(dense_bf16x3_kernel<0>, grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, N, out,
-                       out_stride, out_vec);
+  const int Np = (N + 127) / 128 * 128;
+  const u32x4* wp = static_cast<const u32x4*>(Wp);
+#define REC_B3_GO(XM_, BP_)                                                                                      \
+  hipLaunchKernelGGL((dense_bf16x3_kernel<XM_, BP_>), grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, \
+                     N, out, out_stride, out_vec, wp, Np)
+  if (wp && x_vec != 2) {  // with the transpose-tile x path the prepared form measured slower (1.10 vs 0.88 ms at K = 3341)
+    if (x_vec == 1) REC_B3_GO(1, true);
+    else REC_B3_GO(0, true);
+  } else {
+    if (x_vec == 1) REC_B3_GO(1, false);
+    else if (x_vec == 2) REC_B3_GO(2, false);
+    else REC_B3_GO(0, false);
+  }
+#undef REC_B3_GO
   return true;
+}
+
+int64_t dense_prepared_bytes(int K, int N) {
+  const int64_t K8 = (int64_t)((K + 15) / 16) * 2, Np = (N + 127) / 128 * 128;
+  return K8 * 3 * Np * 16;
+}
+
+void dense_prepare_launch(const float* W, int K, int N, void* Wp, hipStream_t st) {
+  const int K8 = (K + 15) / 16 * 2, Np = (N + 127) / 128 * 128;
+  const int64_t total = (int64_t)K8 * Np;
+  hipLaunchKernelGGL(dense_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, K, N, Np, K8,
+                     static_cast<u32x4*>(Wp));
 }
 
 }  // namespace rec

@@ -127,6 +127,19 @@ PYBIND11_MODULE(_C, m) {
           "rec_dense_f32");
   });
 
+  m.def("dense_prepared_bytes", [](int K, int N) { return rec_dense_prepared_bytes(K, N); });
+  m.def("dense_prepare_f32", [](ptr_t W, int K, int N, ptr_t prepared, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dense_prepare_f32(P<const float>(W), K, N, P<void>(prepared), P<void>(stream)), "rec_dense_prepare_f32");
+  });
+  m.def("dense_prep_f32", [](ptr_t x, int64_t x_stride, ptr_t W, ptr_t prepared, ptr_t bias, ptr_t alpha, int act,
+                             int64_t M, int K, int N, ptr_t out, int64_t out_stride, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dense_prep_f32(P<const float>(x), x_stride, P<const float>(W), P<const void>(prepared),
+                             P<const float>(bias), P<const float>(alpha), act, M, K, N, P<float>(out), out_stride,
+                             P<void>(stream)),
+          "rec_dense_prep_f32");
+  });
   m.def("mha_ctr_f32", [](ptr_t xq, ptr_t xk, ptr_t xv, int64_t B, int N, int din, ptr_t Wq,
                           ptr_t Wk, ptr_t Wv, ptr_t W0, int H, int S, int act, ptr_t out,
                           ptr_t stream) {

@@ -64,5 +64,6 @@ class DeepFM(Model):
         else:
             ops.gather_concat(self._group, sparse_inputs, out=buf)              # :53 (sparse part)
             fm_outputs = self.fm([embeds, sparse_embed])                       # :59
-        deep_outputs = self.dense(self.dnn(embeds))                            # :61-62
+        # the DNN reads the 16-B aligned view that includes the zeroed pad columns (zero rows in its folded kernel)
+        deep_outputs = self.dense(self.dnn(buf[:, :self.pad + self.feature_length], lead_pad=self.pad))  # :61-62
         return ops.add_sigmoid(fm_outputs, deep_outputs)                       # :64

@@ -6,6 +6,7 @@ CPU; tensors that are not on a GPU raise.
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -226,6 +227,24 @@ def fm_onehot(dense: torch.Tensor, ids: torch.Tensor, vocab: Sequence[int], w0: 
     return out
 
 
+# Pre-split weights for the large-layer Dense kernel (rec_dense_prepare_f32): one entry per live weight tensor,
+# keyed by identity and invalidated by torch's in-place version counter; a weakref callback drops the entry with
+# the tensor, so a recycled address can never hit a stale entry.
+_prep_cache = {}
+
+
+def _prepared_weights(W: torch.Tensor) -> torch.Tensor:
+    key = id(W)
+    ent = _prep_cache.get(key)
+    if ent is not None and ent[0]() is W and ent[1] == W._version:
+        return ent[2]
+    K, N = W.shape
+    buf = torch.empty(C.dense_prepared_bytes(K, N), dtype=torch.uint8, device=W.device)
+    C.dense_prepare_f32(W.data_ptr(), K, N, buf.data_ptr(), _stream())
+    _prep_cache[key] = (weakref.ref(W, lambda _r, k=key: _prep_cache.pop(k, None)), W._version, buf)
+    return buf
+
+
 def dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
           alpha: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Keras Dense on the last axis: act(x @ W + bias); x (..., K) with unit inner stride."""
@@ -253,8 +272,9 @@ def dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
         _chk(bias, "bias")
     if alpha is not None:
         _chk(alpha, "alpha")
-    C.dense_f32(x2.data_ptr(), xs, W.data_ptr(), _ptr(bias), _ptr(alpha), _act_id(act), M, K, N, out.data_ptr(),
-                out.stride(0), _stream())
+    prep = _prepared_weights(W) if (M >= 1024 and K * N >= 4096 and not (K <= 64 and N <= 64) and N > 8) else None
+    C.dense_prep_f32(x2.data_ptr(), xs, W.data_ptr(), _ptr(prep), _ptr(bias), _ptr(alpha), _act_id(act), M, K, N,
+                     out.data_ptr(), out.stride(0), _stream())
     return out.view(*lead, N) if out.is_contiguous() and out.shape[1] == N else out
 
 
