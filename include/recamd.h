@@ -193,6 +193,12 @@ int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc* tables, i
  * -4294967296.0 (=> uniform 1/Sk); keys are never masked, not causal; softmax over keys;
  * out = P v merged to (B,Sq,dm).  mask: (B,Sq) fp32.  Sq < Sk serves SASRec's last block, where
  * only the final query row is consumed (src/match/sasrec/model.py:88). */
+/* Same with explicit row strides (floats, multiples of 4, >= dm) for q / k / v: views of a wider buffer, e.g. the
+ * K and V halves of one fused [Wk | Wv] projection.  Batch stride = S * row stride.  Strided operands are served
+ * by the default kernels (Sq <= 8, or Sq >= 16 with dk in {32, 64}); other shapes need contiguous tensors. */
+int rec_mha_rowmask_strided_f32(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
+                                const float* v, int64_t v_stride, const float* mask, int64_t B,
+                                int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out, void* stream);
 int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
                         int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out,
                         void* stream);

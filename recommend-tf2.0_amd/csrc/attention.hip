@@ -316,7 +316,10 @@ __global__ __launch_bounds__(256) void mha_rowmask_kernel(const float* __restric
 }
 
 bool mha_rowmask_b3_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B, int Sq,
-                             int Sk, int dk, int H, float* out, hipStream_t st);
+                             int Sk, int dk, int H, float* out, int64_t qs, int64_t ks, int64_t vs, hipStream_t st);
+bool mha_rowmask_smallq_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B, int Sq,
+                                 int Sk, int dk, int H, float* out, int64_t qs, int64_t ks, int64_t vs,
+                                 hipStream_t st);
 bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
                                int Sq, int Sk, int dk, int H, float* out, hipStream_t st);
 bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
@@ -422,10 +425,15 @@ extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc
   return REC_OK;
 }
 
-extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
-                                   int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H,
-                                   float* out, void* stream) {
+extern "C" int rec_mha_rowmask_strided_f32(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
+                                           const float* v, int64_t v_stride, const float* mask, int64_t B,
+                                           int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out,
+                                           void* stream) {
   const char* who = "rec_mha_rowmask_f32";
+  REC_CHECK_ARG(q_stride >= dm && k_stride >= dm && v_stride >= dm && q_stride % 4 == 0 && k_stride % 4 == 0 &&
+                    v_stride % 4 == 0,
+                REC_ESHAPE, "%s: row strides must be >= dm and multiples of 4 floats", who);
+  const bool contiguous = q_stride == dm && k_stride == dm && v_stride == dm;
   REC_CHECK_ARG(B >= 0 && Sq >= 1 && Sk >= 1 && H >= 1 && dm >= H && dm % H == 0, REC_ESHAPE,
                 "%s: bad shape Sq=%d Sk=%d dm=%d H=%d", who, Sq, Sk, dm, H);
   const int dk = dm / H;
@@ -442,11 +450,17 @@ extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* 
     // sequence-length limit).  REC_MHA_IMPL = "f32" keeps the fp32-MFMA kernel, "valu" the round-1 VALU kernel.
     const char* e = getenv("REC_MHA_IMPL");
     if (!(e && (e[0] == 'v' || e[0] == 'f')) && Sq > 8 &&
-        mha_rowmask_b3_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, st)) {
+        mha_rowmask_b3_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, q_stride, k_stride, v_stride, st)) {
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
+    if (!(e && e[0] == 'v') &&
+        mha_rowmask_smallq_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, q_stride, k_stride, v_stride, st)) {
       REC_CHECK_LAUNCH(who);
       return REC_OK;
     }
   }
+  REC_CHECK_ARG(contiguous, REC_ENOTIMPL, "%s: strided q/k/v need Sq <= 8 or (Sq >= 16 and dk in {32, 64})", who);
   const size_t lds = (size_t)2 * Sk * dk * sizeof(float);
   REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: Sk=%d dk=%d needs %zu B of LDS", who, Sk, dk, lds);
   {
@@ -473,6 +487,12 @@ extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* 
 #undef REC_MHA
   REC_CHECK_LAUNCH(who);
   return REC_OK;
+}
+
+extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
+                                   int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H,
+                                   float* out, void* stream) {
+  return rec_mha_rowmask_strided_f32(q, dm, k, dm, v, dm, mask, B, Sq, Sk, dm, H, out, stream);
 }
 
 // ================================================================================================
@@ -636,7 +656,8 @@ __global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __
                                                                  const float* __restrict__ v,
                                                                  const float* __restrict__ mask, int Sq,
                                                                  int Sk, int H, int64_t total,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, int64_t qs, int64_t ks,
+                                                                 int64_t vs) {
   constexpr int LPK = DK / 4;       // lanes per key
   constexpr int KPS = 64 / LPK;     // keys per wave step
   const int lane = threadIdx.x & 63;
@@ -647,11 +668,11 @@ __global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __
   const int64_t b = bi / Sq;
   const int dm = H * DK;
   const int sub = lane % LPK, grp = lane / LPK;
-  const f32x4 qv = reinterpret_cast<const f32x4*>(q + bi * dm + h * DK)[sub];
+  const f32x4 qv = reinterpret_cast<const f32x4*>(q + bi * qs + h * DK)[sub];
   const bool masked = mask[bi] == 0.f;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)DK);
-  const float* kb = k + b * (int64_t)Sk * dm + h * DK + sub * 4;
-  const float* vb = v + b * (int64_t)Sk * dm + h * DK + sub * 4;
+  const float* kb = k + b * (int64_t)Sk * ks + h * DK + sub * 4;
+  const float* vb = v + b * (int64_t)Sk * vs + h * DK + sub * 4;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;
@@ -661,8 +682,8 @@ __global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __
     for (int u = 0; u < U; ++u) {
       int j = j0 + u * KPS + grp;
       j = j < Sk ? j : Sk - 1;
-      kr[u] = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * dm);
-      vr[u] = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * dm);
+      kr[u] = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ks);
+      vr[u] = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * vs);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -719,19 +740,27 @@ static bool launch_mha_mfma(const float* q, const float* k, const float* v, cons
   return true;
 }
 
+// few query rows: HBM-bound decode-style kernel (takes row strides)
+bool mha_rowmask_smallq_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B, int Sq,
+                                 int Sk, int dk, int H, float* out, int64_t qs, int64_t ks, int64_t vs,
+                                 hipStream_t st) {
+  if (!(Sq <= 8 && (dk == 64 || dk == 32 || dk == 16))) return false;
+  const int64_t total = B * Sq * H;
+  const dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  if (dk == 64)
+    hipLaunchKernelGGL((mha_rowmask_smallq_kernel<64>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out, qs,
+                       ks, vs);
+  else if (dk == 32)
+    hipLaunchKernelGGL((mha_rowmask_smallq_kernel<32>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out, qs,
+                       ks, vs);
+  else
+    hipLaunchKernelGGL((mha_rowmask_smallq_kernel<16>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out, qs,
+                       ks, vs);
+  return true;
+}
+
 bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
                                int Sq, int Sk, int dk, int H, float* out, hipStream_t st) {
-  if (Sq <= 8 && (dk == 64 || dk == 32 || dk == 16)) {  // few query rows: HBM-bound decode-style kernel
-    const int64_t total = B * Sq * H;
-    const dim3 grid((unsigned)((total + 3) / 4)), block(256);
-    if (dk == 64)
-      hipLaunchKernelGGL((mha_rowmask_smallq_kernel<64>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out);
-    else if (dk == 32)
-      hipLaunchKernelGGL((mha_rowmask_smallq_kernel<32>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out);
-    else
-      hipLaunchKernelGGL((mha_rowmask_smallq_kernel<16>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out);
-    return true;
-  }
   if (Sq < 16 || B > 65535) return false;
   if (dk == 64) return launch_mha_mfma<64>(q, k, v, mask, B, Sq, Sk, H, out, st);
   if (dk == 32) return launch_mha_mfma<32>(q, k, v, mask, B, Sq, Sk, H, out, st);

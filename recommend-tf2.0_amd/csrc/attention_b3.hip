@@ -71,7 +71,8 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
                                                                 const float* __restrict__ k,
                                                                 const float* __restrict__ v,
                                                                 const float* __restrict__ mask, int Sq, int Sk, int H,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, int64_t qs, int64_t ks_,
+                                                                int64_t vs) {
   using namespace ab3;
   constexpr int NKS = DK / 16;  // k-steps of QK^T
   constexpr int NDT = DK / 32;  // 32-wide d tiles of the output
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
   const int h = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int dm = H * DK;
-  const float* kb = k + b * (int64_t)Sk * dm + h * DK;
-  const float* vb = v + b * (int64_t)Sk * dm + h * DK;
+  // qs / ks_ / vs: row strides (floats) of q / k / v -- dm when contiguous, larger for views of a fused projection
+  const float* kb = k + b * (int64_t)Sk * ks_ + h * DK;
+  const float* vb = v + b * (int64_t)Sk * vs + h * DK;
   const int nkt = (Sk + 31) >> 5;
   const int nqt = (Sq + 31) >> 5;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)DK);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
     const int key = kt * 32 + s_key;
     if (s_role < 2) {
       if (key < Sk) {
-        const float* p = (s_role == 0 ? kb : vb) + (int64_t)key * dm + s_chunk * 8;
+        const float* p = (s_role == 0 ? kb + (int64_t)key * ks_ : vb + (int64_t)key * vs) + s_chunk * 8;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
         sreg[0] = a0.x, sreg[1] = a0.y, sreg[2] = a0.z, sreg[3] = a0.w;
         sreg[4] = a1.x, sreg[5] = a1.y, sreg[6] = a1.z, sreg[7] = a1.w;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
     // Q operand fragments: lane (query, half) holds Q[query][16 s + 8 half .. +8]
     u32x4 qf[NKS][3];
     {
-      const float* qp = q + (b * Sq + qc) * (int64_t)dm + h * DK + hf * 8;
+      const float* qp = q + (b * Sq + qc) * qs + h * DK + hf * 8;
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(qp + 16 * s), a1 = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4);
@@ -251,18 +253,18 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
 
 // q, k, v, out 16-B aligned with dm % 4 == 0 is the caller's precondition (checked in rec_mha_rowmask_f32)
 bool mha_rowmask_b3_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B, int Sq,
-                             int Sk, int dk, int H, float* out, hipStream_t st) {
+                             int Sk, int dk, int H, float* out, int64_t qs, int64_t ks, int64_t vs, hipStream_t st) {
   if (B > 65535 || H > 65535 || Sq < 16) return false;
   const int nqt = (Sq + 31) / 32;
   const dim3 grid((unsigned)H, (unsigned)B);
   if (dk == 64) {
     // staging needs 2 * 32 * 8 = 512 threads for K + V rows
-    hipLaunchKernelGGL((mha_rowmask_b3_kernel<64>), grid, dim3(512), 0, st, q, k, v, mask, Sq, Sk, H, out);
+    hipLaunchKernelGGL((mha_rowmask_b3_kernel<64>), grid, dim3(512), 0, st, q, k, v, mask, Sq, Sk, H, out, qs, ks, vs);
     return true;
   }
   if (dk == 32) {
     hipLaunchKernelGGL((mha_rowmask_b3_kernel<32>), grid, dim3(nqt > 4 ? 512 : 256), 0, st, q, k, v, mask, Sq, Sk, H,
-                       out);
+                       out, qs, ks, vs);
     return true;
   }
   return false;

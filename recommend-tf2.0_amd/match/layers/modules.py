@@ -49,14 +49,33 @@ class MultiHeadAttention(nn.Layer):
         self.wk = nn.Dense(d_model, activation=None)
         self.wv = nn.Dense(d_model, activation=None)
 
+    def project(self, xq, xk, xv):
+        """wq(xq), wk(xk), wv(xv) (:115-117).  When inputs coincide (self-attention) the Dense layers that share an
+        input run as ONE GEMM over a concatenated kernel [Wq | Wk | Wv] (a cached parameter transform) and the
+        results are column slices of its output: the input is read once instead of two or three times."""
+        for layer, x in ((self.wq, xq), (self.wk, xk), (self.wv, xv)):
+            if not layer.built:
+                layer.build(x.shape[-1])
+        if xk is xv:
+            group = (self.wq, self.wk, self.wv) if xq is xk else (self.wk, self.wv)
+            key = tuple(l._version for l in group) + (len(group),)
+            if getattr(self, '_fused', None) is None or self._fused[0] != key:
+                W = torch.cat([l._w['kernel'] for l in group], dim=1).contiguous()
+                b = torch.cat([l._w['bias'] for l in group], dim=0).contiguous()
+                self._fused = (key, W, b)
+            y = ops.dense(xk, self._fused[1], self._fused[2])
+            d = self.d_model
+            if len(group) == 3:
+                return y[..., :d], y[..., d:2 * d], y[..., 2 * d:]
+            return self.wq(xq), y[..., :d], y[..., d:]
+        return self.wq(xq), self.wk(xk), self.wv(xv)
+
     def call(self, q, k=None, v=None, mask=None, **kwargs):
         k = q if k is None else k
         v = q if v is None else v
-        q = self.wq(q)
-        k = self.wk(k)
-        v = self.wv(v)
+        q, k, v = self.project(q, k, v)
         m = mask.reshape(mask.shape[0], -1).to(torch.float32).contiguous()
-        return ops.mha_rowmask(q.contiguous(), k.contiguous(), v.contiguous(), m, self.num_heads)
+        return ops.mha_rowmask(q, k, v, m, self.num_heads)
 
 
 class FFN(nn.Layer):
@@ -93,11 +112,9 @@ class TransformerEncoder(nn.Layer):
         else:
             xq, mq = query_rows, query_mask
         mha = self.mha
-        q = mha.wq(xq)
-        k = mha.wk(x)
-        v = mha.wv(x)
+        q, k, v = mha.project(xq, x, x)
         m = mq.reshape(mq.shape[0], -1).to(torch.float32).contiguous()
-        att_out = ops.mha_rowmask(q.contiguous(), k.contiguous(), v.contiguous(), m, mha.num_heads)
+        att_out = ops.mha_rowmask(q, k, v, m, mha.num_heads)
         out1 = self.layernorm1(xq, residual=att_out)                         # LN(x + att)
         ffn_out = self.ffn(out1)
         return self.layernorm2(out1, residual=ffn_out, row_mask=out_mask)    # LN(out1 + ffn) [* mask]

@@ -315,21 +315,36 @@ def din_attention_pool(q, k, v, mask, W, bias, act="sigmoid", alpha=None) -> tor
     return out
 
 
+def _row_strided(t: torch.Tensor, nm: str) -> int:
+    """(B, S, dm) tensor whose rows may sit in a wider buffer: unit inner stride, batch stride = S * row stride."""
+    if t.dim() != 3 or t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
+        raise ValueError(f"{nm}: expected (B, S, dm) rows with unit inner stride (a contiguous tensor or a column "
+                         "slice of one)")
+    return t.stride(1)
+
+
 def mha_rowmask(q, k, v, mask, num_heads) -> torch.Tensor:
     """match scaled_dot_product_attention + head split/merge (src/match/layers/modules.py:76-96,
-    119-130) on projected q (B,Sq,dm), k/v (B,Sk,dm); mask (B,Sq) floats (0 = padded query)."""
+    119-130) on projected q (B,Sq,dm), k/v (B,Sk,dm); mask (B,Sq) floats (0 = padded query).
+    q / k / v may be column slices of a wider (B, S, W) buffer (fused projections)."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (mask, "mask")):
         _chk(t, nm)
-        if not t.is_contiguous():
-            raise ValueError(f"{nm}: must be contiguous")
+    if not mask.is_contiguous():
+        raise ValueError("mask: must be contiguous")
+    qs, ks, vs = _row_strided(q, "q"), _row_strided(k, "k"), _row_strided(v, "v")
     B, Sq, dm = q.shape
     Sk = k.shape[1]
+    dk = dm // max(1, num_heads)
+    if (qs != dm or ks != dm or vs != dm) and not (Sq <= 8 or (Sq >= 16 and dk in (32, 64))):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()   # shapes served by the contiguous-only kernels
+        qs = ks = vs = dm
     out = torch.empty((B, Sq, dm), dtype=torch.float32, device=q.device)
     step = 65535
     for b0 in range(0, B, step):  # grid.z limit
         b1 = min(B, b0 + step)
-        C.mha_rowmask_f32(q[b0:b1].data_ptr(), k[b0:b1].data_ptr(), v[b0:b1].data_ptr(), mask[b0:b1].data_ptr(),
-                          b1 - b0, Sq, Sk, dm, num_heads, out[b0:b1].data_ptr(), _stream())
+        C.mha_rowmask_strided_f32(q[b0:b1].data_ptr(), qs, k[b0:b1].data_ptr(), ks, v[b0:b1].data_ptr(), vs,
+                                  mask[b0:b1].data_ptr(), b1 - b0, Sq, Sk, dm, num_heads, out[b0:b1].data_ptr(),
+                                  _stream())
     return out
 
 

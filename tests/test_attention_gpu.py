@@ -177,3 +177,17 @@ def test_gather_din_attention_pool_fused(dev, B, T_, n_tab, Dt, mask_mode):
                                         mask_from_ids=mfi, oob_flag=flag).cpu().numpy()
     assert close(out, ref.din_attention_layer(q, hist, hist, mask_np, W, b, "sigmoid"))
     assert int(flag.item()) == (1 if B > 10 else 0)
+
+
+@pytest.mark.parametrize("B,Sq,Sk,d,H", [(3, 200, 200, 64, 1), (5, 1, 200, 64, 1), (2, 40, 70, 64, 2), (4, 6, 33, 32, 1)])
+def test_mha_rowmask_strided_views(dev, B, Sq, Sk, d, H):
+    """q / k / v as column slices of wider buffers (the fused [Wq | Wk | Wv] projection output) == contiguous."""
+    from recamd import ops
+    rng = np.random.default_rng(B + Sq)
+    kv = T(rng.normal(size=(B, Sk, 2 * d + 8)).astype(np.float32), dev)
+    qb = T(rng.normal(size=(B, Sq, d + 4)).astype(np.float32), dev)
+    mask = T((rng.random((B, Sq)) > 0.3).astype(np.float32), dev)
+    q, k, v = qb[..., 4:], kv[..., :d], kv[..., d + 8:]
+    got = ops.mha_rowmask(q, k, v, mask, H)
+    ref_out = ops.mha_rowmask(q.contiguous(), k.contiguous(), v.contiguous(), mask, H)
+    assert torch.equal(got, ref_out)
