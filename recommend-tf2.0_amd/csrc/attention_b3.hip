@@ -15,8 +15,9 @@
 // rebuilt from six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl, lh, mm): fp32 accuracy at 2.7x the fp32 MFMA peak.
 // (Tried: 4-wave workgroups per group of 4 query tiles so that two share a CU: 0.83 ms against 0.79 ms at config 5 --
 // the second pass over K/V and its splits cost more than the overlap wins.)
-// Staging per key tile: K rows split and written as MFMA fragments [plane][k-step][half][key]; V rows go to an fp32
-// scratch tile first and are read back transposed (8 keys of one feature column) before the split.
+// Staging per key tile: K rows are split and written as MFMA fragments [plane][k-step][half][key]; V rows are split
+// the same way and scattered as 16-bit elements into the transposed fragments [plane][k-step][half][d] (element =
+// key), so one barrier per key tile suffices.
 #include <math.h>
 
 #include "common.h"
@@ -79,7 +80,6 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
   constexpr int NCH = DK / 8;   // 8-float chunks per row
   __shared__ u32x4 Kf[2][3][NKS][2][32];   // [stage][plane][k-step][half][key]
   __shared__ u32x4 Vf[2][3][2][2][DK];     // [stage][plane][k-step][half][d]
-  __shared__ float Vs[32][DK + 4];         // fp32 scratch for the V transpose
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwv = blockDim.x >> 6;
@@ -98,9 +98,6 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
   const int s_role = tid / (32 * NCH);          // 0 = K, 1 = V, >= 2 idle in staging
   const int s_t = tid - s_role * (32 * NCH);
   const int s_key = s_t & 31, s_chunk = s_t >> 5;
-  // V transpose readers: threads [0, 4*DK): d = t % DK, (ks, half) = t / DK
-  const int t_d = tid % DK, t_c = tid / DK;     // t_c < 4 active
-  const int t_ks = t_c >> 1, t_hf = t_c & 1;
 
   float sreg[8];
   auto gload = [&](int kt) {
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
       }
     }
   };
-  auto stage_write = [&](int st) {  // K fragments + V scratch (before the first barrier)
+  auto stage_write = [&](int st) {  // K fragments, V^T fragments
     if (s_role == 0) {
       u32x4 hh, mm, ll;
       split8(sreg, hh, mm, ll);
@@ -125,20 +122,22 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
       Kf[st][1][s_chunk >> 1][s_chunk & 1][s_key] = mm;
       Kf[st][2][s_chunk >> 1][s_chunk & 1][s_key] = ll;
     } else if (s_role == 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Vs[s_key][s_chunk * 8 + j] = sreg[j];
-    }
-  };
-  auto stage_vtrans = [&](int st) {  // after the barrier: 8 keys of one d in the operand's key order
-    if (t_c < 4) {
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = Vs[16 * t_ks + 8 * (j >> 2) + 4 * t_hf + (j & 3)][t_d];
+      // V^T fragments: this thread holds 8 feature columns of ONE key; element (key) j of the fragment of column d
+      // is a 16-bit slot, key -> (k-step, half, j) by the accumulator-order map 16 ks + 8 (j >> 2) + 4 half + (j & 3)
       u32x4 hh, mm, ll;
-      split8(x, hh, mm, ll);
-      Vf[st][0][t_ks][t_hf][t_d] = hh;
-      Vf[st][1][t_ks][t_hf][t_d] = mm;
-      Vf[st][2][t_ks][t_hf][t_d] = ll;
+      split8(sreg, hh, mm, ll);
+      const int ks = s_key >> 4, rem = s_key & 15;
+      const int vhf = (rem >> 2) & 1, j = ((rem >> 3) << 2) | (rem & 3);
+      uint16_t* vh = reinterpret_cast<uint16_t*>(&Vf[st][0][ks][vhf][s_chunk * 8]) + j;
+      uint16_t* vm = reinterpret_cast<uint16_t*>(&Vf[st][1][ks][vhf][s_chunk * 8]) + j;
+      uint16_t* vl = reinterpret_cast<uint16_t*>(&Vf[st][2][ks][vhf][s_chunk * 8]) + j;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int sh = 16 * (e & 1);
+        vh[e * 8] = (uint16_t)(hh[e >> 1] >> sh);
+        vm[e * 8] = (uint16_t)(mm[e >> 1] >> sh);
+        vl[e * 8] = (uint16_t)(ll[e >> 1] >> sh);
+      }
     }
   };
 
@@ -169,8 +168,6 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
     __syncthreads();  // previous round's last tile fully consumed before its stage is overwritten
     gload(0);
     stage_write(0);
-    __syncthreads();
-    stage_vtrans(0);
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -229,11 +226,7 @@ __global__ __launch_bounds__(512, 2) void mha_rowmask_b3_kernel(const float* __r
           }
         }
       }
-      if (kt + 1 < nkt) {
-        stage_write(st ^ 1);   // stage st^1 was last read in iteration kt-1 (two barriers ago)
-        __syncthreads();
-        stage_vtrans(st ^ 1);
-      }
+      if (kt + 1 < nkt) stage_write(st ^ 1);  // stage st^1 was last read in iteration kt-1 (one barrier ago)
       __syncthreads();
     }
     // ---- write O: lane = query, register r of tile t = column t*32 + (r&3) + 8(r>>2) + 4 hf
