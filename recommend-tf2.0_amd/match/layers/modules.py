@@ -112,9 +112,25 @@ class TransformerEncoder(nn.Layer):
         else:
             xq, mq = query_rows, query_mask
         mha = self.mha
-        q, k, v = mha.project(xq, x, x)
         m = mq.reshape(mq.shape[0], -1).to(torch.float32).contiguous()
-        att_out = ops.mha_rowmask(q, k, v, m, mha.num_heads)
+        if query_rows is not None and mha.num_heads == 1 and xq.shape[1] <= 8:
+            # Few query rows, one head: the K and V projections of all S positions are not needed.
+            #   q . k_j = q . (x_j Wk + bk) = x_j . (Wk q) + const   (a per-query constant does not change the softmax)
+            #   sum_j p_j (x_j Wv + bv)     = (sum_j p_j x_j) Wv + bv  (the p_j sum to 1)
+            # so the attention runs over the RAW sequence rows with the query pulled back through Wk, and only the
+            # pooled row is projected by Wv: one pass over x instead of a (B*S, d) x (d, 2d) GEMM plus two passes.
+            for layer, t in ((mha.wq, xq), (mha.wk, x), (mha.wv, x)):
+                if not layer.built:
+                    layer.build(t.shape[-1])
+            key = mha.wk._version
+            if getattr(self, '_wk_t', None) is None or self._wk_t[0] != key:
+                self._wk_t = (key, mha.wk._w['kernel'].t().contiguous())
+            q_back = ops.dense(mha.wq(xq), self._wk_t[1])                     # (B, Sq, d_in) = Wk q
+            pooled = ops.mha_rowmask(q_back, x, x, m, 1)                      # softmax(q_back . x_j / sqrt(d)) x_j
+            att_out = mha.wv(pooled)
+        else:
+            q, k, v = mha.project(xq, x, x)
+            att_out = ops.mha_rowmask(q, k, v, m, mha.num_heads)
         out1 = self.layernorm1(xq, residual=att_out)                         # LN(x + att)
         ffn_out = self.ffn(out1)
         return self.layernorm2(out1, residual=ffn_out, row_mask=out_mask)    # LN(out1 + ffn) [* mask]
