@@ -199,6 +199,13 @@ int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc* tables, i
 int rec_mha_rowmask_strided_f32(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
                                 const float* v, int64_t v_stride, const float* mask, int64_t B,
                                 int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out, void* stream);
+/* Few query rows (Sq <= 8) against keys = values = rows of ONE embedding table addressed by ids (B, Sk): the fused
+ * form of `seq_embed = Embedding(seq) * mask` followed by the attention of SASRec's last block
+ * (src/match/sasrec/model.py:75,81-88) — the (B, Sk, dm) sequence tensor is never written or re-read.  ids outside
+ * [0, vocab) (e.g. pad ids remapped to -1) read as zero rows; keys are never masked, query rows by `mask`. */
+int rec_gather_mha_fewq_f32(const float* q, int64_t q_stride, const float* table, int32_t vocab, const void* ids,
+                            int32_t ids_dtype, const float* mask, int64_t B, int32_t Sq, int32_t Sk, int32_t dm,
+                            int32_t H, float* out, void* stream);
 int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
                         int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out,
                         void* stream);

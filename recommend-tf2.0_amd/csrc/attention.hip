@@ -320,6 +320,9 @@ bool mha_rowmask_b3_dispatch(const float* q, const float* k, const float* v, con
 bool mha_rowmask_smallq_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B, int Sq,
                                  int Sk, int dk, int H, float* out, int64_t qs, int64_t ks, int64_t vs,
                                  hipStream_t st);
+void mha_gather_fewq_dispatch(const float* q, int64_t q_stride, const float* table, int vocab, const void* ids,
+                              bool ids_f32, const float* mask, int64_t B, int Sq, int Sk, int dk, int H, float* out,
+                              hipStream_t st);
 bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,
                                int Sq, int Sk, int dk, int H, float* out, hipStream_t st);
 bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
@@ -489,6 +492,26 @@ extern "C" int rec_mha_rowmask_strided_f32(const float* q, int64_t q_stride, con
   return REC_OK;
 }
 
+extern "C" int rec_gather_mha_fewq_f32(const float* q, int64_t q_stride, const float* table, int32_t vocab,
+                                       const void* ids, int32_t ids_dtype, const float* mask, int64_t B,
+                                       int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out, void* stream) {
+  const char* who = "rec_gather_mha_fewq_f32";
+  REC_CHECK_ARG(B >= 0 && Sq >= 1 && Sq <= 8 && Sk >= 1 && H >= 1 && dm >= H && dm % H == 0 && vocab >= 1, REC_ESHAPE,
+                "%s: bad shape Sq=%d (1..8) Sk=%d dm=%d H=%d vocab=%d", who, Sq, Sk, dm, H, vocab);
+  const int dk = dm / H;
+  REC_CHECK_ARG(dk == 16 || dk == 32 || dk == 64, REC_ESHAPE, "%s: head depth %d not in {16,32,64}", who, dk);
+  REC_CHECK_ARG(ids_dtype == REC_IDS_I32 || ids_dtype == REC_IDS_F32, REC_EINVAL, "%s: bad ids_dtype", who);
+  REC_CHECK_ARG(q_stride >= dm && q_stride % 4 == 0, REC_ESHAPE, "%s: bad q_stride", who);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(q && table && ids && mask && out, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(aligned16(q) && aligned16(table) && aligned16(out), REC_EINVAL, "%s: q/table/out must be 16-B aligned",
+                who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  mha_gather_fewq_dispatch(q, q_stride, table, vocab, ids, ids_dtype == REC_IDS_F32, mask, B, Sq, Sk, dk, H, out, st);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
 extern "C" int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const float* mask,
                                    int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H,
                                    float* out, void* stream) {
@@ -650,14 +673,18 @@ __global__ __launch_bounds__(512) void mha_rowmask_mfma_kernel(const float* __re
 // key (16 B each), 64/LPK keys per wave step, one online-softmax state per lane group, merged at
 // the end by a butterfly over the group index.
 // ------------------------------------------------------------------------------------------------
-template <int DK>
+// GATHER: k == v == rows of one embedding table addressed by ids (B, Sk) (`k` = table base, `ks` = its row stride
+// = dm, `v` unused); ids outside [0, vocab) read as zero rows (the pad rows of `seq_embed * mask`,
+// src/match/sasrec/model.py:81-82).  The (B, Sk, dm) sequence tensor is then never written or re-read.
+template <int DK, bool GATHER = false, int IDS_F32 = 0>
 __global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
                                                                  const float* __restrict__ v,
                                                                  const float* __restrict__ mask, int Sq,
                                                                  int Sk, int H, int64_t total,
                                                                  float* __restrict__ out, int64_t qs, int64_t ks,
-                                                                 int64_t vs) {
+                                                                 int64_t vs, const void* __restrict__ ids = nullptr,
+                                                                 int vocab = 0) {
   constexpr int LPK = DK / 4;       // lanes per key
   constexpr int KPS = 64 / LPK;     // keys per wave step
   const int lane = threadIdx.x & 63;
@@ -671,8 +698,8 @@ __global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + bi * qs + h * DK)[sub];
   const bool masked = mask[bi] == 0.f;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)DK);
-  const float* kb = k + b * (int64_t)Sk * ks + h * DK + sub * 4;
-  const float* vb = v + b * (int64_t)Sk * vs + h * DK + sub * 4;
+  const float* kb = GATHER ? k + h * DK + sub * 4 : k + b * (int64_t)Sk * ks + h * DK + sub * 4;
+  const float* vb = GATHER ? nullptr : v + b * (int64_t)Sk * vs + h * DK + sub * 4;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;
@@ -682,8 +709,16 @@ __global__ __launch_bounds__(256) void mha_rowmask_smallq_kernel(const float* __
     for (int u = 0; u < U; ++u) {
       int j = j0 + u * KPS + grp;
       j = j < Sk ? j : Sk - 1;
-      kr[u] = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ks);
-      vr[u] = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * vs);
+      if constexpr (GATHER) {
+        const int32_t id = load_id<IDS_F32>(ids, b * (int64_t)Sk + j);
+        const bool ok = (uint32_t)id < (uint32_t)vocab;
+        const f32x4 row = *reinterpret_cast<const f32x4*>(kb + (int64_t)(ok ? id : 0) * ks);
+        kr[u] = ok ? row : f32x4{0.f, 0.f, 0.f, 0.f};
+        vr[u] = kr[u];
+      } else {
+        kr[u] = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ks);
+        vr[u] = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * vs);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -757,6 +792,21 @@ bool mha_rowmask_smallq_dispatch(const float* q, const float* k, const float* v,
     hipLaunchKernelGGL((mha_rowmask_smallq_kernel<16>), grid, block, 0, st, q, k, v, mask, Sq, Sk, H, total, out, qs,
                        ks, vs);
   return true;
+}
+
+void mha_gather_fewq_dispatch(const float* q, int64_t q_stride, const float* table, int vocab, const void* ids,
+                              bool ids_f32, const float* mask, int64_t B, int Sq, int Sk, int dk, int H, float* out,
+                              hipStream_t st) {
+  const int64_t total = B * Sq * H;
+  const dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  const int64_t dm = (int64_t)dk * H;
+#define REC_GMHA(DK_, F_)                                                                                             \
+  hipLaunchKernelGGL((mha_rowmask_smallq_kernel<DK_, true, F_>), grid, block, 0, st, q, table, (const float*)nullptr, \
+                     mask, Sq, Sk, H, total, out, q_stride, dm, dm, ids, vocab)
+  if (dk == 64) { if (ids_f32) REC_GMHA(64, 1); else REC_GMHA(64, 0); }
+  else if (dk == 32) { if (ids_f32) REC_GMHA(32, 1); else REC_GMHA(32, 0); }
+  else { if (ids_f32) REC_GMHA(16, 1); else REC_GMHA(16, 0); }
+#undef REC_GMHA
 }
 
 bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, const float* mask, int64_t B,

@@ -175,6 +175,13 @@ PYBIND11_MODULE(_C, m) {
                 "rec_gather_din_attn_pool_f32");
         });
 
+  m.def("gather_mha_fewq_f32", [](ptr_t q, int64_t qs, ptr_t table, int vocab, ptr_t ids, int ids_dtype, ptr_t mask,
+                                  int64_t B, int Sq, int Sk, int dm, int H, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_gather_mha_fewq_f32(P<const float>(q), qs, P<const float>(table), vocab, P<const void>(ids), ids_dtype,
+                                  P<const float>(mask), B, Sq, Sk, dm, H, P<float>(out), P<void>(stream)),
+          "rec_gather_mha_fewq_f32");
+  });
   m.def("mha_rowmask_strided_f32", [](ptr_t q, int64_t qs, ptr_t k, int64_t ks, ptr_t v, int64_t vs, ptr_t mask,
                                       int64_t B, int Sq, int Sk, int dm, int H, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;

@@ -105,7 +105,10 @@ class TransformerEncoder(nn.Layer):
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
 
-    def call(self, inputs, query_rows=None, query_mask=None, out_mask=None, **kwargs):
+    def call(self, inputs, query_rows=None, query_mask=None, out_mask=None, gather=None, **kwargs):
+        """gather=(table, ids): the keys/values are table[ids] (ids (B,S), out-of-range -> zero rows) and `x` may be
+        None — only valid together with query_rows on the few-rows/one-head path, where the sequence tensor is then
+        never materialised."""
         x, mask = inputs
         if query_rows is None:
             xq, mq = x, mask
@@ -119,14 +122,17 @@ class TransformerEncoder(nn.Layer):
             #   sum_j p_j (x_j Wv + bv)     = (sum_j p_j x_j) Wv + bv  (the p_j sum to 1)
             # so the attention runs over the RAW sequence rows with the query pulled back through Wk, and only the
             # pooled row is projected by Wv: one pass over x instead of a (B*S, d) x (d, 2d) GEMM plus two passes.
-            for layer, t in ((mha.wq, xq), (mha.wk, x), (mha.wv, x)):
+            for layer in (mha.wq, mha.wk, mha.wv):
                 if not layer.built:
-                    layer.build(t.shape[-1])
+                    layer.build(xq.shape[-1])
             key = mha.wk._version
             if getattr(self, '_wk_t', None) is None or self._wk_t[0] != key:
                 self._wk_t = (key, mha.wk._w['kernel'].t().contiguous())
             q_back = ops.dense(mha.wq(xq), self._wk_t[1])                     # (B, Sq, d_in) = Wk q
-            pooled = ops.mha_rowmask(q_back, x, x, m, 1)                      # softmax(q_back . x_j / sqrt(d)) x_j
+            if gather is not None:
+                pooled = ops.gather_mha_fewq(q_back, gather[0], gather[1], m, 1)
+            else:
+                pooled = ops.mha_rowmask(q_back, x, x, m, 1)                  # softmax(q_back . x_j / sqrt(d)) x_j
             att_out = mha.wv(pooled)
         else:
             q, k, v = mha.project(xq, x, x)

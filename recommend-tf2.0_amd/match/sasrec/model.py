@@ -52,10 +52,21 @@ class SASRec(Model):
         # :75 + :81-82 in one pass: `seq_embed * mask` zeroes exactly the rows whose id is 0, so pad ids
         # are sent to the gather as out-of-range (-1) and read as zero rows (finite tables: identical)
         seq_m = torch.where(seq_inputs == 0, torch.full_like(seq_inputs, -1), seq_inputs)
-        att_outputs = self.user_embed_layers['embed_seq_item'](seq_m)                     # (B,S,d)
         nb = len(self.encoder_layer)
         seq_info = None
-        for i, block in enumerate(self.encoder_layer):
+        seq_layer = self.user_embed_layers['embed_seq_item']
+        if nb == 1 and self.last_row_only and self.encoder_layer[0].mha.num_heads == 1 and \
+                self.d_model in (16, 32, 64) and seq_m.dtype == torch.int32:
+            # one block, last row only, one head: the attention reads the item table directly by id (fused lookup),
+            # only the last position's embedding is materialised (query row + residual)
+            last = seq_layer(seq_m[:, -1:].contiguous())                                  # (B,1,d)
+            seq_info = self.encoder_layer[0]([None, mask], query_rows=last, query_mask=mask[:, -1:].contiguous(),
+                                             out_mask=mask[:, -1].contiguous(),
+                                             gather=(seq_layer.table, seq_m.contiguous()))[:, 0, :]
+            nb = 0
+        else:
+            att_outputs = seq_layer(seq_m)                                                # (B,S,d)
+        for i, block in enumerate(self.encoder_layer[:nb] if nb else []):
             if i == nb - 1 and self.last_row_only:
                 seq_info = block([att_outputs, mask], query_rows=att_outputs[:, -1:, :].contiguous(),
                                  query_mask=mask[:, -1:].contiguous(),

@@ -348,6 +348,25 @@ def mha_rowmask(q, k, v, mask, num_heads) -> torch.Tensor:
     return out
 
 
+def gather_mha_fewq(q, table, ids, mask, num_heads) -> torch.Tensor:
+    """Attention of a few query rows q (B, Sq <= 8, dm) over keys = values = table[ids] (ids (B, Sk); out-of-range
+    ids are zero rows), without materialising the (B, Sk, dm) sequence tensor.  mask (B, Sq): 0 = padded query."""
+    _chk(q, "q")
+    _chk(table, "table")
+    _chk(mask, "mask")
+    ids = _rows2d(_chk(ids, "ids", None), "ids")
+    if not (table.is_contiguous() and mask.is_contiguous() and ids.is_contiguous()):
+        raise ValueError("gather_mha_fewq: table, ids and mask must be contiguous")
+    qs = _row_strided(q, "q")
+    B, Sq, dm = q.shape
+    if table.shape[1] != dm or ids.shape[0] != B:
+        raise ValueError("gather_mha_fewq: inconsistent shapes")
+    out = torch.empty((B, Sq, dm), dtype=torch.float32, device=q.device)
+    C.gather_mha_fewq_f32(q.data_ptr(), qs, table.data_ptr(), table.shape[0], ids.data_ptr(), _ids_dtype(ids),
+                          mask.data_ptr(), B, Sq, ids.shape[1], dm, num_heads, out.data_ptr(), _stream())
+    return out
+
+
 def layernorm_residual(x, r, gamma, beta, eps, row_mask=None) -> torch.Tensor:
     """LayerNormalization(x + r) over the last axis [* row_mask] (src/match/layers/modules.py:175,183)."""
     _chk(x, "x")

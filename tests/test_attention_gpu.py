@@ -191,3 +191,21 @@ def test_mha_rowmask_strided_views(dev, B, Sq, Sk, d, H):
     got = ops.mha_rowmask(q, k, v, mask, H)
     ref_out = ops.mha_rowmask(q.contiguous(), k.contiguous(), v.contiguous(), mask, H)
     assert torch.equal(got, ref_out)
+
+
+@pytest.mark.parametrize("B,Sq,Sk,d,H,fids", [(9, 1, 200, 64, 1, False), (4, 3, 50, 64, 2, False), (6, 8, 33, 32, 1, True),
+                                              (3, 2, 17, 16, 1, False)])
+def test_gather_mha_fewq_matches_unfused(dev, B, Sq, Sk, d, H, fids):
+    """fused table lookup + few-query attention == gather (out-of-range ids -> zero rows) then the plain kernel"""
+    from recamd import ops
+    rng = np.random.default_rng(B + Sk)
+    V = 40
+    table = T(rng.normal(size=(V, d)).astype(np.float32), dev)
+    ids_np = rng.integers(-1, V + 1, size=(B, Sk))                       # includes -1 (pad) and V (out of range)
+    ids = T(ids_np.astype(np.float32 if fids else np.int32), dev)
+    q = T(rng.normal(size=(B, Sq, d)).astype(np.float32), dev)
+    mask = T((rng.random((B, Sq)) > 0.3).astype(np.float32), dev)
+    x = ops.gather_concat(ops.TableGroup([table]), ids.reshape(B * Sk, 1).contiguous()).reshape(B, Sk, d)
+    exp = ops.mha_rowmask(q, x, x, mask, H)
+    got = ops.gather_mha_fewq(q, table, ids, mask, H)
+    assert torch.equal(got, exp)
