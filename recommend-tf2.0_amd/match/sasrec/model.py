@@ -42,7 +42,7 @@ class SASRec(Model):
         self.encoder_layer = [self.track('encoder_%d' % i, TransformerEncoder(
             self.d_model, num_heads, ffn_hidden_unit, dnn_dropout, layer_norm_eps)) for i in range(blocks)]
         self.last_row_only = last_row_only
-        self.losses = []
+        self._logits = None
         self.embed = None
 
     def call(self, inputs, **kwargs):
@@ -81,8 +81,14 @@ class SASRec(Model):
                               out=logits[:, :1])                                          # :77,:90
         ops.gather_dot_scores(seq_info, self.user_embed_layers['embed_neg_item'].table, neg_inputs,
                               out=logits[:, 1:])                                          # :79,:91
-        pos_scores, neg_scores = logits[:, :1], logits[:, 1:]
-        losses = torch.mean(-torch.log(torch.sigmoid(pos_scores)) -
-                            torch.log(1 - torch.sigmoid(neg_scores))) / 2                 # :93-94
-        self.losses = [losses]
+        self._logits = logits          # the add_loss value (:93-95) is computed on demand: `model.losses`
         return logits                                                                     # :96
+
+    @property
+    def losses(self):
+        """[mean(-log sigmoid(pos) - log(1 - sigmoid(neg))) / 2] of the last call (src/match/sasrec/model.py:93-95;
+        (B,1) + (B,neg) broadcasting).  Lazy: a forward pass used for scoring does not pay for it."""
+        if self._logits is None:
+            return []
+        pos_scores, neg_scores = self._logits[:, :1], self._logits[:, 1:]
+        return [torch.mean(-torch.log(torch.sigmoid(pos_scores)) - torch.log(1 - torch.sigmoid(neg_scores))) / 2]
