@@ -128,6 +128,24 @@ __global__ __launch_bounds__(256) void dense_narrow_kernel(const float* __restri
 }
 
 
+// N == 1 (the final Dense(1) of every ctr model), aligned rows: 16 lanes per row with 16-B loads, 4 rows per wave
+__global__ __launch_bounds__(256) void dense_vec1_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ alpha, int act, int64_t M, int K,
+                                                         float* __restrict__ out, int64_t out_stride) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const int64_t rc = row < M ? row : M - 1;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + rc * x_stride);
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(W);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k4 = sub; k4 < (K >> 2); k4 += 16) acc += xr[k4] * w4[k4];
+  float s = acc.x + acc.y + acc.z + acc.w;
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (sub == 0 && row < M) out[row * out_stride] = act_apply(s + (bias ? bias[0] : 0.f), act, alpha ? alpha[0] : 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny Dense (K <= 128, N <= 128): the layers of this zoo are narrow (64x64 attention projections,
 // 64<->128 FFN, 32..256-wide towers) while M is huge (batch x seq), so the op is HBM-bound:
@@ -340,7 +358,10 @@ static int dense_impl_f32(const char* who, const float* x, int64_t x_stride, con
     REC_CHECK_LAUNCH(who);
     return REC_OK;
   }
-  if (N <= 8) {
+  if (N == 1 && (K & 3) == 0 && aligned16(x) && aligned16(W) && x_stride % 4 == 0) {
+    hipLaunchKernelGGL(dense_vec1_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, x, x_stride, W, bias, alpha,
+                       act, M, K, out, out_stride);
+  } else if (N <= 8) {
     hipLaunchKernelGGL((dense_narrow_kernel<8>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x,
                        x_stride, W, bias, alpha, act, M, K, N, out, out_stride);
   } else {
