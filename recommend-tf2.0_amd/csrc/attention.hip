@@ -328,6 +328,9 @@ bool mha_rowmask_mfma_dispatch(const float* q, const float* k, const float* v, c
 bool mha_ctr_mfma_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din,
                            const float* Wq, const float* Wk, const float* Wv, const float* W0, int H, int S,
                            int act, float* out, hipStream_t st);
+bool mha_ctr_b3_dispatch(const float* xq, const float* xk, const float* xv, int64_t B, int N, int din, const float* Wq,
+                         const float* Wk, const float* Wv, const float* W0, int H, int S, int act, float* out,
+                         hipStream_t st);
 
 }  // namespace rec
 
@@ -343,7 +346,14 @@ extern "C" int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv
   if (B == 0) return REC_OK;
   REC_CHECK_ARG(xq && xk && xv && Wq && Wk && Wv && out, REC_EINVAL, "%s: NULL pointer", who);
   {
-    const char* e = getenv("REC_MHA_IMPL");  // "valu" forces the LDS/VALU kernel (A/B only)
+    // default: bf16x3 kernel (attention_ctr_b3.hip) for the AutoInt shapes; REC_MHA_IMPL = "f32" keeps the fp32-MFMA
+    // kernel, "valu" the LDS/VALU kernel (A/B only)
+    const char* e = getenv("REC_MHA_IMPL");
+    if (!(e && (e[0] == 'v' || e[0] == 'f')) && mha_ctr_b3_dispatch(xq, xk, xv, B, N, din, Wq, Wk, Wv, W0, H, S, act, out,
+                                                                     reinterpret_cast<hipStream_t>(stream))) {
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
     if (!(e && e[0] == 'v') && mha_ctr_mfma_dispatch(xq, xk, xv, B, N, din, Wq, Wk, Wv, W0, H, S, act, out,
                                                      reinterpret_cast<hipStream_t>(stream))) {
       REC_CHECK_LAUNCH(who);
