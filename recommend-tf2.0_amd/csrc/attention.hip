@@ -209,37 +209,60 @@ __global__ __launch_bounds__(256) void din_gather_pool_kernel(const float* __res
   const int64_t idbase = b * (int64_t)T * n_tab;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = z4;
+  // Padded slots get the logit -2^32+1: as soon as ONE real slot exists their softmax weight underflows to exactly 0
+  // (exp(-4e9) = 0 in fp32), so their rows need not be fetched at all -- with pre-padded histories of random length
+  // that is half of the traffic.  Only if every slot is padded do all rows count (uniform weights).  The slot flags
+  // of 64 positions at a time come from one coalesced id / mask load and a ballot.
+  auto is_pad = [&](int t) -> bool {
+    if (mask_mode == 0) return true;                                      // non-tensor mask: all padded
+    if (mask_mode == 1) return mask[b * T + t] == 0.f;
+    return load_id<IDS_F32>(ids, idbase + (int64_t)t * n_tab) == 0;       // slot real iff first id != 0
+  };
+  bool any_real = false;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    any_real = any_real || __any(t < T && !is_pad(t));
+  }
   constexpr int U = 4;  // 8 measured slower (0.197 vs 0.146 ms at config 4)
-  for (int t0 = 0; t0 < T; t0 += U) {
-    f32x4 kr[U];
-    int32_t id0[U];
-#pragma unroll
-    for (int e = 0; e < U; ++e) {
-      const int t = t0 + e < T ? t0 + e : T - 1;
-      const int32_t id = load_id<IDS_F32>(ids, idbase + (int64_t)t * n_tab + tab);
-      id0[e] = load_id<IDS_F32>(ids, idbase + (int64_t)t * n_tab);
-      const bool ok = (uint32_t)id < tvocab;
-      if (!ok && on && oob) *oob = 1;
-      const f32x4 row = *reinterpret_cast<const f32x4*>(tbase + (int64_t)(ok ? id : 0) * Dt + col);
-      kr[e] = (on && ok) ? row : z4;
+  for (int tb0 = 0; tb0 < T; tb0 += 64) {
+    const int tl = tb0 + lane;
+    const bool padl = tl < T ? is_pad(tl) : true;
+    const uint64_t padmask = __ballot(padl);
+    if (oob && tl < T) {  // out-of-range ids are reported for every slot, fetched or skipped (ids are 1.5 % of the bytes)
+      bool bad = false;
+      for (int c = 0; c < n_tab; ++c)
+        bad = bad || (uint32_t)load_id<IDS_F32>(ids, idbase + (int64_t)tl * n_tab + c) >= (uint32_t)tb.vocab[c];
+      if (bad) *oob = 1;
     }
+    uint64_t todo = __ballot(tl < T && (!padl || !any_real));             // slots whose rows matter
+    while (todo) {
+      f32x4 kr[U];
+      int tt[U];
 #pragma unroll
-    for (int e = 0; e < U; ++e) {
-      if (t0 + e >= T) break;
-      const f32x4 pr = kr[e] * u;
-      float s = wave_sum(pr.x + pr.y + pr.z + pr.w) + c0;
-      s = act_apply(s, act, al);
-      bool pad;
-      if (mask_mode == 0) pad = true;                                   // non-tensor mask: all padded
-      else if (mask_mode == 1) pad = mask[b * T + t0 + e] == 0.f;
-      else pad = id0[e] == 0;                                           // slot real iff first id != 0
-      if (pad) s = kNegPad;
-      const float mn = fmaxf(m, s);
-      const float sc = expf(m - mn);
-      const float p = expf(s - mn);
-      acc = acc * sc + kr[e] * p;
-      l = l * sc + p;
-      m = mn;
+      for (int e = 0; e < U; ++e) {
+        const int bit = todo ? __builtin_ctzll(todo) : -1;                // wave-uniform
+        tt[e] = bit;
+        if (bit >= 0) todo &= todo - 1;
+        const int t = tb0 + (bit >= 0 ? bit : 0);
+        const int32_t id = load_id<IDS_F32>(ids, idbase + (int64_t)t * n_tab + tab);
+        const bool ok = (uint32_t)id < tvocab;
+        const f32x4 row = *reinterpret_cast<const f32x4*>(tbase + (int64_t)(ok ? id : 0) * Dt + col);
+        kr[e] = (on && ok) ? row : z4;
+      }
+#pragma unroll
+      for (int e = 0; e < U; ++e) {
+        if (tt[e] < 0) break;
+        const f32x4 pr = kr[e] * u;
+        float s = wave_sum(pr.x + pr.y + pr.z + pr.w) + c0;
+        s = act_apply(s, act, al);
+        if ((padmask >> tt[e]) & 1) s = kNegPad;
+        const float mn = fmaxf(m, s);
+        const float sc = expf(m - mn);
+        const float p = expf(s - mn);
+        acc = acc * sc + kr[e] * p;
+        l = l * sc + p;
+        m = mn;
+      }
     }
   }
   if (on) reinterpret_cast<f32x4*>(out + b * d)[lane] = acc * (1.f / l);
