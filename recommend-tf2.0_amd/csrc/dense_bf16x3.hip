@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ alpha, int act, int64_t M,
                                                               int K, int N, float* __restrict__ out,
-                                                              int64_t out_stride, int out_vec, const u32x4* __restrict__ Wp, int Np) {
+                                                              int64_t out_stride, int out_vec, const u32x4* __restrict__ Wp, int Np,
+                                                              int xcd_map) {
   using namespace b3;
   constexpr int x_vec = XMODE;
   // [stage][operand A/B][plane h/m/l][kh][row] of 16-B fragments: 2*2*3*2*128*16 B = 48 KiB
@@ -73,8 +74,27 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int l32 = lane & 31, half = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // Workgroup -> tile map, XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2),
+  // so XCD c gets the M tiles c, c + 8, ... and walks ALL column tiles of one M tile back to back: the x tile is
+  // fetched from HBM once and the other column blocks hit it in that XCD's L2 (instead of every column block
+  // re-reading x from HBM -- with x taken out of the loop the same kernel runs at 2.2x the rate).
+  const int ntn = (N + BN - 1) / BN;
+  const int64_t ntm = (M + BM - 1) / BM;
+  const int64_t L = blockIdx.x;
+  int64_t mt;
+  int nt_;
+  if (xcd_map) {
+    const int xcd = (int)(L & 7);
+    const int64_t slot = L >> 3;
+    mt = (slot / ntn) * 8 + xcd;
+    nt_ = (int)(slot % ntn);
+  } else {  // few rows, wide W: M tiles fastest, so that the workgroups in flight share a W column block
+    mt = L % ntm;
+    nt_ = (int)(L / ntm);
+  }
+  if (mt >= ntm || nt_ >= ntn) return;  // padding workgroups of the last group of 8 M tiles
+  const int64_t m0 = mt * BM;
+  const int n0 = nt_ * BN;
   const int srow = tid & 127, skh = tid >> 7;
   const int64_t gm = m0 + srow;
   const int gn = n0 + srow;
@@ -262,13 +282,16 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
   // x staging: 1 = two dwordx4 per thread (aligned rows), 2 = coalesced along k + LDS transpose (unaligned rows,
   // K large enough to pay for the extra barrier), 0 = scalar loads per thread (unaligned, short K)
   const int x_vec = (aligned16(x) && x_stride % 4 == 0) ? 1 : (K >= 64 ? 2 : 0);
-  const dim3 grid((unsigned)gx, (unsigned)gy);
+  const int xcd_map = M >= 4 * (int64_t)N ? 1 : 0;  // x is the big operand: keep its tile in one XCD's L2
+  const int64_t total = ((gx + 7) / 8) * 8 * gy;  // M tiles padded to a multiple of 8 (one per XCD)
+  if (total > 0x7fffffffLL) return false;
+  const dim3 grid((unsigned)total);
   const int out_vec = (aligned16(out) && out_stride % 4 == 0 && N % 4 == 0) ? 1 : 0;
   const int Np = (N + 127) / 128 * 128;
   const u32x4* wp = static_cast<const u32x4*>(Wp);
 #define REC_B3_GO(XM_, BP_)                                                                                      \
   hipLaunchKernelGGL((dense_bf16x3_kernel<XM_, BP_>), grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, \
-                     N, out, out_stride, out_vec, wp, Np)
+                     N, out, out_stride, out_vec, wp, Np, xcd_map)
   if (wp && x_vec != 2) {  // with the transpose-tile x path the prepared form measured slower (1.10 vs 0.88 ms at K = 3341)
     if (x_vec == 1) REC_B3_GO(1, true);
     else REC_B3_GO(0, true);
