@@ -20,6 +20,7 @@
 // key), so one barrier per key tile suffices.
 #include <math.h>
 
+#include "bf16x3.h"
 #include "common.h"
 
 namespace rec {
@@ -30,28 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace ab3 {
-__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ float bfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
-  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-}
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  uint32_t r1[8], lo[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float hf = bfloat(fbits(x[j]) & 0xffff0000u);
-    const float r = x[j] - hf;
-    const float mf = bfloat(fbits(r) & 0xffff0000u);
-    r1[j] = fbits(r);
-    lo[j] = fbits(r - mf);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    h[t] = pack_top16(fbits(x[2 * t]), fbits(x[2 * t + 1]));
-    m[t] = pack_top16(r1[2 * t], r1[2 * t + 1]);
-    l[t] = pack_top16(lo[2 * t], lo[2 * t + 1]);
-  }
-}
+using bf16x3::split8;
 __device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
   const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), am = __builtin_bit_cast(bf16x8, a[1]),
                al = __builtin_bit_cast(bf16x8, a[2]);

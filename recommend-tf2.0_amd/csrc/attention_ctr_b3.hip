@@ -18,6 +18,7 @@
 // exactly into three bf16 terms and each product rebuilt from six MFMAs (hh, hm, mh, hl, lh, mm): fp32 accuracy.
 #include <math.h>
 
+#include "bf16x3.h"
 #include "common.h"
 
 namespace rec {
@@ -27,38 +28,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace cb3 {
-__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ float bfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
-  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-}
 struct Frag {  // three bf16x8 planes
   u32x4 p[3];
 };
-// n floats (n = 4 or 8) -> planes; unused elements are zero
 template <int NV>
 __device__ __forceinline__ Frag split(const float* x) {
-  uint32_t hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < NV) {
-      const float hf = bfloat(fbits(x[j]) & 0xffff0000u);
-      const float r = x[j] - hf;
-      const float mf = bfloat(fbits(r) & 0xffff0000u);
-      hb[j] = fbits(x[j]);
-      mb[j] = fbits(r);
-      lb[j] = fbits(r - mf);
-    } else {
-      hb[j] = mb[j] = lb[j] = 0u;
-    }
-  }
   Frag f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    f.p[0][t] = pack_top16(hb[2 * t], hb[2 * t + 1]);
-    f.p[1][t] = pack_top16(mb[2 * t], mb[2 * t + 1]);
-    f.p[2][t] = pack_top16(lb[2 * t], lb[2 * t + 1]);
-  }
+  bf16x3::split<NV>(x, f.p[0], f.p[1], f.p[2]);
   return f;
 }
 __device__ __forceinline__ Frag split4(const f32x4 a) {

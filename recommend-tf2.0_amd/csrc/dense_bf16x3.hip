@@ -15,6 +15,7 @@
 // compute phase is 12 conflict-free ds_read_b128 per 24 MFMAs.  LDS is double-buffered, one barrier per k-step.
 // Epilogue: bias + activation, then each wave transposes its 64 x 64 tile through LDS so that it leaves as 16-B
 // row-major stores (65 536 x 13 x 512, an output-bound layer: 0.046 -> 0.033 ms).
+#include "bf16x3.h"
 #include "common.h"
 
 namespace rec {
@@ -27,29 +28,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace b3 {
 constexpr int BM = 128, BN = 128, BK = 16;
 
-__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ float bfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
-  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-}
-// 8 fp32 -> three bf16x8 fragments with x = h + m + l exactly
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  uint32_t r1[8], lo[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float hf = bfloat(fbits(x[j]) & 0xffff0000u);
-    const float r = x[j] - hf;
-    const float mf = bfloat(fbits(r) & 0xffff0000u);
-    r1[j] = fbits(r);
-    lo[j] = fbits(r - mf);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    h[t] = pack_top16(fbits(x[2 * t]), fbits(x[2 * t + 1]));
-    m[t] = pack_top16(r1[2 * t], r1[2 * t + 1]);
-    l[t] = pack_top16(lo[2 * t], lo[2 * t + 1]);
-  }
-}
+using bf16x3::split8;
 }  // namespace b3
 
 // XMODE: 1 = aligned x rows (two dwordx4 per thread), 2 = unaligned rows via the borrowed transpose tile,

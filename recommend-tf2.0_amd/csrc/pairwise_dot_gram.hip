@@ -38,6 +38,7 @@
 // Epilogue: the 32x32 accumulator tile has column j on the lane and row i in the register, so each lane writes
 // its strictly-lower-triangle entries to their output slot i(i-1)/2 + j in a wave-private LDS row, the dense
 // passthrough is appended, and the row leaves as aligned nontemporal 16-B stores.
+#include "bf16x3.h"
 #include "common.h"
 
 namespace rec {
@@ -69,32 +70,11 @@ constexpr int GRAM_STAGE = 3904;  // floats of output staging per wave (4 waves:
 #define REC_GRAM_BATCH 8  // output rows staged per wave before one flush (capped by GRAM_STAGE / row size)
 #endif
 
-__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ float bfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
-// low half = top 16 bits of lo, high half = top 16 bits of hi
-__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
-  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-}
-
-// 8 fp32 -> three bf16x8 fragments with x = h + m + l exactly
+// 8 fp32 (two float4) -> three bf16x8 fragments with x = h + m + l exactly (bf16x3.h)
 __device__ __forceinline__ void split8(const f32x4 a0, const f32x4 a1, bf16x8& H, bf16x8& M, bf16x8& L) {
-  float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  uint32_t r1[8], lo[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float hf = bfloat(fbits(x[j]) & 0xffff0000u);
-    const float r = x[j] - hf;  // exact
-    const float mf = bfloat(fbits(r) & 0xffff0000u);
-    r1[j] = fbits(r);
-    lo[j] = fbits(r - mf);  // exact, <= 8 significant bits
-  }
+  const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
   u32x4 h, m, l;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    h[t] = pack_top16(fbits(x[2 * t]), fbits(x[2 * t + 1]));
-    m[t] = pack_top16(r1[2 * t], r1[2 * t + 1]);
-    l[t] = pack_top16(lo[2 * t], lo[2 * t + 1]);
-  }
+  bf16x3::split8(x, h, m, l);
   H = __builtin_bit_cast(bf16x8, h);
   M = __builtin_bit_cast(bf16x8, m);
   L = __builtin_bit_cast(bf16x8, l);
