@@ -78,6 +78,20 @@ int rec_gather_concat_f32(const rec_table_desc* tables, int32_t F,
                           int64_t B, float* out, int64_t out_stride,
                           int32_t* oob_flag, void* stream);
 
+/* Fused K1 + nv dot products per sample: emb_out gets the gathered concat row (as rec_gather_concat_f32) and
+ * out_dots[b, v] = <row b, Wd[v, 0:width]> for nv <= 8 weight vectors Wd (nv, width) row-major, width % 4 == 0 and
+ * >= the concat width (columns that no table writes must be zero in Wd).  DCN's cross tower in closed form:
+ * x_l = alpha_l x0 + sum_{j<l} b_j (src/ctr/layers/modules.py:105-112) only needs d_l = x0 . w_l, and since
+ * cross_x only meets Dense(1) afterwards (src/ctr/dcn/model.py:55-56) it is never materialised:
+ * rec_dcn_logit_f32 evaluates, per sample, alpha = 1; alpha += alpha d_l + G_l (l < L);
+ * out = sigmoid(alpha d_L + c + extra[b])  with the weight-only constants G_l = sum_{j<l} b_j . w_l,
+ * c = (sum_j b_j) . w_c + bias, d_L = x0 . w_c and extra = dnn_x . w_d. */
+int rec_gather_dots_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                        int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
+                        float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag, void* stream);
+int rec_dcn_logit_f32(const float* dots, int32_t L, const float* G, float c, const float* extra, int64_t B,
+                      float* out, void* stream);
+
 /* ---- a5 / K5: DLRM pairwise-dot interaction ---------------------------------------------------
  * The reference's DLRM.call (src/ctr/dlrm/model.py:42-54) has no interaction op; this is the
  * interaction of the paper the file cites (src/ctr/dlrm/model.py:7):

@@ -220,6 +220,22 @@ PYBIND11_MODULE(_C, m) {
                 "rec_gather_dot_scores_f32");
         });
 
+  m.def("gather_dots_f32",
+        [](const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, int64_t ids_stride, ptr_t Wd, int nv,
+           int width, int64_t B, ptr_t emb_out, int64_t emb_stride, ptr_t out_dots, ptr_t oob, ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_dots_f32(d.data(), (int32_t)d.size(), P<const void>(ids), ids_dtype, ids_stride,
+                                    P<const float>(Wd), nv, width, B, P<float>(emb_out), emb_stride,
+                                    P<float>(out_dots), P<int32_t>(oob), P<void>(stream)),
+                "rec_gather_dots_f32");
+        });
+  m.def("dcn_logit_f32", [](ptr_t dots, int L, ptr_t G, float c, ptr_t extra, int64_t B, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dcn_logit_f32(P<const float>(dots), L, P<const float>(G), c, P<const float>(extra), B, P<float>(out),
+                            P<void>(stream)),
+          "rec_dcn_logit_f32");
+  });
   m.def("add_sigmoid_f32", [](ptr_t a, ptr_t b, int64_t n, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_add_sigmoid_f32(P<const float>(a), P<const float>(b), n, P<float>(out), P<void>(stream)),

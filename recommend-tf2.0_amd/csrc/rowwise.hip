@@ -527,6 +527,79 @@ __global__ __launch_bounds__(256) void gather_dot_generic_kernel(
   if (lane == 0) out[b * out_stride + j] = acc;
 }
 
+// K1 + NV dot products per sample, in one pass over the gathered rows: out_dots[b, v] = <concat row b, Wd[v, :]>.
+// DCN's whole cross tower reduces to this (closed form: x_l = alpha_l x0 + sum_{j<l} b_j needs only d_l = x0 . w_l),
+// and because the cross output only meets Dense(1) afterwards, cross_x is never materialised either:
+//   logit = alpha_L (x0 . w_c) + (sum_j b_j) . w_c + dnn_x . w_d + bias      (rec_dcn_logit_f32).
+// LPR lanes own a sample (16 B of every row each); the NV weight vectors live in LDS (NV * width * 4 B per workgroup).
+template <int LPR, int IDS_F32, int NV>
+__global__ __launch_bounds__(256) void gather_dots_kernel(TableSet ts, const void* __restrict__ ids, int64_t ids_stride,
+                                                          int F, const float* __restrict__ Wd, int width, int64_t B,
+                                                          float* __restrict__ emb_out, int64_t emb_stride,
+                                                          float* __restrict__ out_dots, int* __restrict__ oob) {
+  constexpr int D = LPR * 4;
+  constexpr int SPW = 64 / LPR;
+  extern __shared__ __attribute__((aligned(16))) float wsh[];  // [NV][width]
+  for (int e = threadIdx.x * 4; e < NV * width; e += 256 * 4)
+    *reinterpret_cast<f32x4*>(wsh + e) = *reinterpret_cast<const f32x4*>(Wd + e);  // width % 4 == 0, Wd 16-B aligned
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int sl = lane % LPR, sw = lane / LPR;
+  const int64_t b_raw = ((int64_t)blockIdx.x * 4 + wv) * SPW + sw;
+  const bool live = b_raw < B;
+  const int64_t b = live ? b_raw : B - 1;
+  float acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+  constexpr int U = 8;
+  for (int f0 = 0; f0 < F; f0 += U) {
+    f32x4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u < F ? f0 + u : F - 1;
+      const int32_t id = load_id<IDS_F32>(ids, b * ids_stride + f);
+      const bool ok = (uint32_t)id < (uint32_t)ts.vocab[f];
+      if (!ok && oob && live) *oob = 1;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(ts.base[f] + (int64_t)(ok ? id : 0) * D + sl * 4);
+      r[u] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u;
+      if (f < F) {
+        const int oc = ts.out_col[f] + sl * 4;
+        if (live) __builtin_nontemporal_store(r[u], reinterpret_cast<f32x4*>(emb_out + b * emb_stride + oc));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsh + v * width + oc);
+          acc[v] = fmaf(r[u].x, w4.x, fmaf(r[u].y, w4.y, fmaf(r[u].z, w4.z, fmaf(r[u].w, w4.w, acc[v]))));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    float a = acc[v];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (live && sl == 0) out_dots[b * NV + v] = a;
+  }
+}
+
+// per sample: alpha = 1; for l < L: alpha += alpha * d[l] + G[l];  out = sigmoid(alpha * d[L] + c + extra[b])
+__global__ __launch_bounds__(256) void dcn_logit_kernel(const float* __restrict__ dots, int L, const float* __restrict__ G,
+                                                        float c, const float* __restrict__ extra, int64_t B,
+                                                        float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* d = dots + b * (L + 1);
+  float alpha = 1.f;
+  for (int l = 0; l < L; ++l) alpha += alpha * d[l] + G[l];
+  const float z = alpha * d[L] + c + (extra ? extra[b] : 0.f);
+  out[b] = 1.f / (1.f + expf(-z));
+}
+
 // ---- tiny elementwise epilogues ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_sigmoid_kernel(const float* __restrict__ a,
                                                           const float* __restrict__ b, int64_t n,
@@ -948,6 +1021,79 @@ extern "C" int rec_gather_dot_scores_f32(const float* seq_info, int64_t seq_stri
                        seq_info, seq_stride, table->base, (int32_t)table->vocab, d, ids, ids_stride,
                        n, B, out, out_stride, oob_flag);
   }
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_gather_dots_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                                   int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
+                                   float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag,
+                                   void* stream) {
+  const char* who = "rec_gather_dots_f32";
+  TableSet ts;
+  int rc = fill_table_set(tables, F, &ts, who);
+  if (rc != REC_OK) return rc;
+  const int D = tables[0].dim;
+  const int lpr = D / 4;
+  REC_CHECK_ARG(D % 4 == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0, REC_ESHAPE,
+                "%s: D=%d (need D/4 a power of two <= 64)", who, D);
+  int maxcol = 0;
+  for (int f = 0; f < F; ++f) {
+    REC_CHECK_ARG(tables[f].dim == D && aligned16(tables[f].base) && tables[f].out_col % 4 == 0, REC_ESHAPE,
+                  "%s: tables must share dim, be 16-B aligned, out_col %% 4 == 0", who);
+    if (tables[f].out_col + D > maxcol) maxcol = tables[f].out_col + D;
+  }
+  REC_CHECK_ARG(ids_dtype == REC_IDS_I32 || ids_dtype == REC_IDS_F32, REC_EINVAL, "%s: bad ids_dtype", who);
+  REC_CHECK_ARG(nv >= 1 && nv <= 8 && width >= maxcol && width % 4 == 0 && B >= 0 && ids_stride >= F, REC_ESHAPE,
+                "%s: bad shape nv=%d (1..8) width=%d", who, nv, width);
+  const size_t lds = (size_t)nv * width * sizeof(float);
+  REC_CHECK_ARG(lds <= 64 * 1024, REC_ESHAPE, "%s: nv * width * 4 = %zu B of LDS (> 64 KiB)", who, lds);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(ids && Wd && emb_out && out_dots, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(aligned16(emb_out) && emb_stride % 4 == 0 && aligned16(Wd), REC_EINVAL,
+                "%s: emb_out / Wd must be 16-B aligned, emb_stride %% 4 == 0", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int spw = 64 / lpr;
+  const int64_t waves = (B + spw - 1) / spw;
+  const int64_t blocks = (waves + 3) / 4;
+  REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "%s: batch too large", who);
+#define REC_GD3(L_, I_, V_)                                                                                       \
+  hipLaunchKernelGGL((gather_dots_kernel<L_, I_, V_>), dim3((unsigned)blocks), dim3(256), lds, st, ts, ids, ids_stride, \
+                     F, Wd, width, B, emb_out, emb_stride, out_dots, oob_flag)
+#define REC_GD2(L_, I_)                                                            \
+  switch (nv) {                                                                    \
+    case 1: REC_GD3(L_, I_, 1); break;                                             \
+    case 2: REC_GD3(L_, I_, 2); break;                                             \
+    case 3: REC_GD3(L_, I_, 3); break;                                             \
+    case 4: REC_GD3(L_, I_, 4); break;                                             \
+    case 5: REC_GD3(L_, I_, 5); break;                                             \
+    case 6: REC_GD3(L_, I_, 6); break;                                             \
+    case 7: REC_GD3(L_, I_, 7); break;                                             \
+    default: REC_GD3(L_, I_, 8); break;                                            \
+  }
+#define REC_GD1(L_)                                                   \
+  case L_:                                                            \
+    if (ids_dtype == REC_IDS_F32) { REC_GD2(L_, 1) } else { REC_GD2(L_, 0) } \
+    break;
+  switch (lpr) {
+    REC_GD1(1) REC_GD1(2) REC_GD1(4) REC_GD1(8) REC_GD1(16) REC_GD1(32) REC_GD1(64)
+    default: break;
+  }
+#undef REC_GD1
+#undef REC_GD2
+#undef REC_GD3
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_dcn_logit_f32(const float* dots, int32_t L, const float* G, float c, const float* extra, int64_t B,
+                                 float* out, void* stream) {
+  const char* who = "rec_dcn_logit_f32";
+  REC_CHECK_ARG(B >= 0 && L >= 0 && L <= 7, REC_ESHAPE, "%s: B=%lld L=%d", who, (long long)B, L);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(dots && out && (L == 0 || G), REC_EINVAL, "%s: NULL pointer", who);
+  hipLaunchKernelGGL(dcn_logit_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dots, L, G, c, extra, B, out);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }

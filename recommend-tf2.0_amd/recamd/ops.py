@@ -428,6 +428,42 @@ def unpermute_rows(rows: torch.Tensor, perm: torch.Tensor, out: Optional[torch.T
     return out
 
 
+def gather_dots(group: TableGroup, ids: torch.Tensor, Wd: torch.Tensor, out: Optional[torch.Tensor] = None,
+                oob_flag: Optional[torch.Tensor] = None):
+    """gather_concat + dots[b, v] = <concat row b, Wd[v]> for up to 8 weight vectors Wd (nv, width), in one pass.
+    Returns (concat rows (B, >= group.width), dots (B, nv))."""
+    ids = _rows2d(_chk(ids, "ids", None), "ids")
+    _rows2d(_chk(Wd, "Wd"), "Wd")
+    F = len(group)
+    B = ids.shape[0]
+    nv, width = Wd.shape
+    if ids.shape[1] != F or F > C.MAX_TABLES or not Wd.is_contiguous():
+        raise ValueError("gather_dots: inconsistent shapes")
+    if out is None:
+        out = torch.empty((B, (group.width + 3) // 4 * 4), dtype=torch.float32, device=ids.device)[:, :group.width]
+    dots = torch.empty((B, nv), dtype=torch.float32, device=ids.device)
+    C.gather_dots_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0), Wd.data_ptr(), nv, width, B,
+                      out.data_ptr(), out.stride(0), dots.data_ptr(), _ptr(oob_flag), _stream())
+    return out, dots
+
+
+def dcn_logit(dots: torch.Tensor, G: torch.Tensor, c: float, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sigmoid(alpha_L * dots[:, L] + c + extra) with alpha from the closed-form cross recurrence (rec_dcn_logit_f32)."""
+    dots = _chk(dots, "dots").contiguous()
+    G = _chk(G, "G").contiguous()
+    B, L1 = dots.shape
+    if G.numel() != L1 - 1:
+        raise ValueError("dcn_logit: G must have one entry per cross layer")
+    if extra is not None:
+        extra = _chk(extra, "extra").contiguous().reshape(-1)
+        if extra.numel() != B:
+            raise ValueError("dcn_logit: extra must have one value per sample")
+    out = torch.empty((B, 1), dtype=torch.float32, device=dots.device)
+    C.dcn_logit_f32(dots.data_ptr(), L1 - 1, G.data_ptr() if L1 > 1 else 0, float(c), _ptr(extra), B, out.data_ptr(),
+                    _stream())
+    return out
+
+
 def add_sigmoid(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """sigmoid(a + b), elementwise (final logits of DeepFM / DCN / DLRM)."""
     _chk(a, "a")

@@ -144,3 +144,39 @@ def test_gather_fm_fused(dev, B, F, D, nd):
     assert np.array_equal(buf[:, pad + nd:].cpu().numpy(), emb)
     first = np.concatenate([dense, emb], axis=1)
     assert close(out, ref.fm_layer(first, emb, w))
+
+
+@pytest.mark.parametrize("B,F,D,nv", [(1, 3, 8, 1), (300, 26, 16, 4), (129, 5, 128, 8), (64, 26, 128, 4)])
+def test_gather_dots_and_dcn_logit(dev, B, F, D, nv):
+    """fused gather + per-sample dot products, and the closed-form cross/Dense(1) logit built on them, vs the oracle's
+    literal CrossNetwork recurrence followed by the final Dense(1) over [cross_x, dnn_x]"""
+    from recamd import ops
+    rng = np.random.default_rng(B + F + D)
+    V = 30
+    tables = [rng.normal(size=(V, D)).astype(np.float32) * 0.3 for _ in range(F)]
+    ids = rng.integers(-1, V + 1, size=(B, F)).astype(np.int32)
+    dim = F * D
+    Wd = (rng.normal(size=(nv, dim)) / np.sqrt(dim)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    g = ops.TableGroup([t(x) for x in tables])
+    x, dots = ops.gather_dots(g, t(ids), t(Wd))
+    ex = ref.gather_concat([a.astype(np.float64) for a in tables], ids)
+    assert np.array_equal(x.cpu().numpy(), ex.astype(np.float32))
+    assert close(dots.cpu().numpy(), ex @ Wd.astype(np.float64).T)
+    # DCN logit: L = nv - 1 cross layers, last vector = the cross half of the final Dense(1)
+    L = nv - 1
+    cb = (rng.normal(size=(L, dim)) * 0.1).astype(np.float32)
+    H = 7
+    dnn_x = rng.normal(size=(B, H)).astype(np.float32)
+    w_d = rng.normal(size=(H, 1)).astype(np.float32)
+    bias = np.float32(0.3)
+    cross = ref.cross_network(ex, Wd[:L], cb) if L > 0 else ex
+    logit = cross @ Wd[L].astype(np.float64) + (dnn_x.astype(np.float64) @ w_d.astype(np.float64))[:, 0] + bias
+    csum = np.cumsum(cb.astype(np.float64), axis=0) if L > 0 else np.zeros((0, dim))
+    G = np.zeros(L)
+    for l in range(1, L):
+        G[l] = csum[l - 1] @ Wd[l].astype(np.float64)
+    c = (csum[-1] @ Wd[L].astype(np.float64) if L > 0 else 0.0) + bias
+    extra = t(dnn_x) @ t(w_d)
+    got = ops.dcn_logit(dots, t(G.astype(np.float32)), float(c), extra).cpu().numpy()
+    assert close(got[:, 0], ref.sigmoid(logit))
