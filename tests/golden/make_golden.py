@@ -39,6 +39,15 @@ CASES = {
     "dlrm_dot": lambda z: ref.pairwise_dot(np.concatenate(
         [ref.gather_concat(_tables(z, int(z["F"])), z["ids"]).reshape(z["ids"].shape[0], int(z["F"]), -1),
          z["dense"][:, None, :]], axis=1)),
+    # --- widened scope: DCN end to end, retrieval top-k, Adam step, BCE + AUC
+    "dcn": lambda z: ref.dcn_forward(z["ids"], _tables(z, int(z["F"])), z["cW"], z["cB"],   # 2 cross layers = len(hidden_units)
+                                     dict(layers=[(z["W0"], z["b0"]), (z["W1"], z["b1"])],
+                                          bn=dict(gamma=z["bn_g"], beta=z["bn_b"], mean=z["bn_m"], var=z["bn_v"])),
+                                     (z["Wf"], z["bf"])),
+    "topk": lambda z: ref.topk_inner_product(z["q"], z["items"], int(z["k"]))[0],
+    "adam": lambda z: np.stack(ref.adam_step(z["var"], z["m"], z["v"], z["grad"], int(z["step"]), lr=float(z["lr"]),
+                                             l2=float(z["l2"]))),
+    "bce_auc": lambda z: np.array([ref.binary_crossentropy(z["y"], z["p"]), ref.keras_auc(z["y"], z["p"])]),
 }
 
 
@@ -87,6 +96,28 @@ def build_inputs():
     d["dense"] = f32(rng.random((10, 128)))
     d["F"] = np.int32(26)
     cases["dlrm_dot"] = d
+    # ---- cases added later draw from their own generator so that the files above stay byte-identical
+    rng2 = np.random.default_rng(20260102)
+    f2 = lambda a: np.asarray(a, np.float32)  # noqa: E731
+    F, D, V, B = 6, 8, 25, 20
+    dim = F * D
+    d = {f"table_{i}": f2(rng2.uniform(-0.5, 0.5, size=(V, D))) for i in range(F)}
+    d.update(ids=rng2.integers(0, V, size=(B, F)).astype(np.int32), F=np.int32(F),
+             cW=f2(rng2.normal(size=(2, dim)) * 0.2), cB=f2(rng2.normal(size=(2, dim)) * 0.1),
+             W0=f2(rng2.normal(size=(dim, 16)) * 0.2), b0=f2(rng2.normal(size=16) * 0.1),
+             W1=f2(rng2.normal(size=(16, 8)) * 0.2), b1=f2(rng2.normal(size=8) * 0.1),
+             bn_g=f2(1 + 0.1 * rng2.normal(size=dim)), bn_b=f2(rng2.normal(size=dim) * 0.1),
+             bn_m=f2(rng2.normal(size=dim) * 0.1), bn_v=f2(rng2.uniform(0.5, 1.5, size=dim)),
+             Wf=f2(rng2.normal(size=(dim + 8, 1)) * 0.2), bf=f2([0.05]))
+    cases["dcn"] = d
+    cases["topk"] = dict(q=f2(rng2.normal(size=(37, 32))), items=f2(rng2.normal(size=(300, 32))), k=np.int32(10))
+    n = 1000
+    cases["adam"] = dict(var=f2(rng2.normal(size=n) * 0.05), m=f2(rng2.normal(size=n) * 0.01),
+                         v=f2(rng2.random(n) * 1e-3), grad=f2(rng2.normal(size=n) * (rng2.random(n) < 0.3)),
+                         step=np.int32(3), lr=np.float32(1e-3), l2=np.float32(1e-4))
+    y = (rng2.random(4000) < 0.3).astype(np.float32)
+    p = 1.0 / (1.0 + np.exp(-(rng2.normal(size=4000) + 1.2 * (2 * y - 1))))
+    cases["bce_auc"] = dict(y=y, p=f2(p))
     return cases
 
 

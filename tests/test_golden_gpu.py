@@ -104,3 +104,48 @@ def test_golden_sasrec(dev):
         f'{p}/layernorm2/gamma': z["b0_ln2_g"], f'{p}/layernorm2/beta': z["b0_ln2_b"]})
     out = m([z["seq"], z["pos"], z["neg"]]).cpu().numpy()
     assert close(out, z["expected"], 2e-5)
+
+
+def test_golden_dcn(dev):
+    """whole DCN forward (fused gather + dots, closed-form cross / Dense(1) logit) against the fixture produced by the
+    oracle's literal CrossNetwork recurrence + concat + Dense(1); layer_num = len(hidden_units) = 2 (dcn/model.py:32)"""
+    from ctr.dcn.model import DCN
+    z = load("dcn")
+    F = int(z["F"])
+    V, D = z["table_0"].shape
+    m = DCN([{'feat': f'C{i}', 'feat_num': V, 'embed_dim': D} for i in range(F)], hidden_units=[16, 8])
+    m(z["ids"])
+    w = {f'embed_{i}/embeddings': z[f"table_{i}"] for i in range(F)}
+    w.update({'cross_network/cross_weights': z["cW"], 'cross_network/cross_bias': z["cB"],
+              'dnn_network/dense_0/kernel': z["W0"], 'dnn_network/dense_0/bias': z["b0"],
+              'dnn_network/dense_1/kernel': z["W1"], 'dnn_network/dense_1/bias': z["b1"],
+              'dnn_network/bn/gamma': z["bn_g"], 'dnn_network/bn/beta': z["bn_b"], 'dnn_network/bn/moving_mean': z["bn_m"],
+              'dnn_network/bn/moving_variance': z["bn_v"], 'dense_final/kernel': z["Wf"], 'dense_final/bias': z["bf"]})
+    m.set_weights(w)
+    assert close(m(z["ids"]).cpu().numpy(), z["expected"])
+
+
+def test_golden_topk(dev):
+    from recamd import ops
+    z = load("topk")
+    D, I = ops.topk_inner_product(T(z["q"], dev), T(z["items"], dev), int(z["k"]))
+    assert close(D.cpu().numpy(), z["expected"])
+    s = np.einsum('qkd,qd->qk', z["items"][I.cpu().numpy()].astype(np.float64), z["q"].astype(np.float64))
+    assert close(s, z["expected"])
+
+
+def test_golden_adam(dev):
+    from recamd import ops
+    z = load("adam")
+    var, m, v = T(z["var"], dev), T(z["m"], dev), T(z["v"], dev)
+    ops.adam_step(var, m, v, T(z["grad"], dev), int(z["step"]), lr=float(z["lr"]), l2=float(z["l2"]))
+    got = np.stack([var.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()])
+    assert close(got, z["expected"])
+
+
+def test_golden_bce_auc(dev):
+    from recamd import ops
+    z = load("bce_auc")
+    y, p = T(z["y"], dev), T(z["p"], dev)
+    got = np.array([float(ops.binary_crossentropy(y, p).cpu()), float(ops.auc(y, p).cpu())])
+    assert close(got, z["expected"])
