@@ -14,7 +14,8 @@
 // Every fp32 operand (Q, K, V and the probabilities) is split exactly into three bf16 terms and each product is
 // rebuilt from six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl, lh, mm): fp32 accuracy at 2.7x the fp32 MFMA peak.
 // (Tried: 4-wave workgroups per group of 4 query tiles so that two share a CU: 0.83 ms against 0.79 ms at config 5 --
-// the second pass over K/V and its splits cost more than the overlap wins.)
+// the second pass over K/V and its splits cost more than the overlap wins; forcing 128 VGPRs (30 spilled) to fit two
+// 8-wave workgroups per CU: 0.90 ms.)
 // Staging per key tile: K rows are split and written as MFMA fragments [plane][k-step][half][key]; V rows are split
 // the same way and scattered as 16-bit elements into the transposed fragments [plane][k-step][half][d] (element =
 // key), so one barrier per key tile suffices.
