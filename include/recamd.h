@@ -317,6 +317,13 @@ int rec_auc_f32(const float* y_true, const float* y_pred, int64_t n, float* out,
 int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
                     int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
                     int64_t* out_idx, void* stream);
+/* Same with a caller-owned workspace of rec_topk_ip_workspace_bytes(Q, N, k) bytes (0 = none needed): with few queries
+ * (a MovieLens-sized evaluation: 6 040 users x 3 706 items) the item range is split over several workgroups per query
+ * tile and the partial lists are merged by a second kernel; results are identical (same tie rule). */
+int64_t rec_topk_ip_workspace_bytes(int64_t Q, int64_t N, int32_t k);
+int rec_topk_ip_ws_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
+                       int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
+                       int64_t* out_idx, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

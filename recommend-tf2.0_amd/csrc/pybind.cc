@@ -302,6 +302,14 @@ PYBIND11_MODULE(_C, m) {
     check(rec_auc_f32(P<const float>(y), P<const float>(p), n, P<float>(out), P<void>(ws), P<void>(stream)),
           "rec_auc_f32");
   });
+  m.def("topk_ip_workspace_bytes", [](int64_t Q, int64_t N, int k) { return rec_topk_ip_workspace_bytes(Q, N, k); });
+  m.def("topk_ip_ws_f32", [](ptr_t q, int64_t q_stride, int64_t Q, ptr_t items, int64_t items_stride, int64_t N, int d,
+                             int k, ptr_t out_scores, ptr_t out_idx, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_topk_ip_ws_f32(P<const float>(q), q_stride, Q, P<const float>(items), items_stride, N, d, k,
+                             P<float>(out_scores), P<int64_t>(out_idx), P<void>(ws), P<void>(stream)),
+          "rec_topk_ip_ws_f32");
+  });
   m.def("topk_ip_f32", [](ptr_t q, int64_t q_stride, int64_t Q, ptr_t items, int64_t items_stride, int64_t N, int d,
                           int k, ptr_t out_scores, ptr_t out_idx, ptr_t stream) {
     py::gil_scoped_release nogil;

@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restr
                                                             const float* __restrict__ items, int64_t items_stride,
                                                             int64_t Q, int N, int d, int k,
                                                             float* __restrict__ out_scores,
-                                                            int64_t* __restrict__ out_idx, int vec_ok) {
+                                                            int64_t* __restrict__ out_idx, int vec_ok, int n_chunk,
+                                                            float* __restrict__ part_s, int* __restrict__ part_i) {
+  // n_chunk > 0 (split-N, few queries): workgroup (x, y) scans items [y * n_chunk, (y+1) * n_chunk) and writes its
+  // k best per query to part_s / part_i [y][Q][k]; topk_merge_kernel combines the gridDim.y partial lists.
   using namespace topk;
   using namespace tb3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -242,13 +245,15 @@ __global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restr
       Bf[((ks * 3 + 2) * 2 + skh) * 128 + srow] = l;
     }
   };
-  if (N > 0) gload(0);
+  const int n_begin = n_chunk > 0 ? (int)blockIdx.y * n_chunk : 0;
+  const int n_end = n_chunk > 0 ? (n_begin + n_chunk < N ? n_begin + n_chunk : N) : N;
+  if (n_begin < n_end) gload(n_begin);
   __syncthreads();
 
-  for (int n0 = 0; n0 < N; n0 += BN) {
+  for (int n0 = n_begin; n0 < n_end; n0 += BN) {
     lwrite();
     __syncthreads();
-    if (n0 + BN < N) gload(n0 + BN);
+    if (n0 + BN < n_end) gload(n0 + BN);
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -296,6 +301,67 @@ __global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restr
       if (!__any(cand)) continue;  // wave-uniform: neither of the two rows of this register has a candidate
       v[4] = l32 < k ? run_s[row * KMAX + l32] : -INFINITY;
       id[4] = l32 < k ? run_i[row * KMAX + l32] : -1;
+      // Few candidates (the common case once the lists have warmed up): insert them one by one into the sorted list
+      // held by lanes 0..k-1 of the half-wave -- position = number of entries that beat the candidate (one ballot),
+      // entries behind it move down one lane.  ~25 instructions per candidate instead of k arg-max rounds.
+      {
+        int ncand = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ncand += better(v[j], id[j], thr, thr_i) ? 1 : 0;
+        const uint64_t anyc = __ballot(ncand > 0);
+        const int cntA = __popcll(anyc & 0xffffffffull), cntB = __popcll(anyc >> 32);
+        // lanes hold up to 4 candidates each; bound the work by the number of candidate LANES times 4
+        if (cntA <= 4 && cntB <= 4) {   // wave-uniform
+          float ls = v[4];
+          int li = id[4];
+          for (int it = 0; it < 16; ++it) {
+            bool have = false;
+            float cs = -INFINITY;
+            int ci = -1, cj = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (id[j] >= 0 && better(v[j], id[j], cs, ci)) cs = v[j], ci = id[j], cj = j, have = true;
+            // still a candidate against the CURRENT k-th entry of my half's list?
+            const float kth_s = __shfl(ls, (lane & 32) + k - 1);
+            const int kth_i = __shfl(li, (lane & 32) + k - 1);
+            have = have && better(cs, ci, kth_s, kth_i);
+            const uint64_t hm = __ballot(have);
+            if (hm == 0) break;         // wave-uniform
+            const uint64_t mine = half ? (hm >> 32) : (hm & 0xffffffffull);
+            const int src = mine ? (int)__builtin_ctzll(mine) : 0;       // lowest lane of my half with a candidate
+            const float xs = __shfl(cs, (lane & 32) + src);
+            const int xi = __shfl(ci, (lane & 32) + src);
+            const bool active = mine != 0;
+            if (active && l32 == src && cj >= 0) {                        // the owner retires that slot
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (j == cj) v[j] = -INFINITY, id[j] = -1;
+            }
+            // position in the sorted list: entries that beat x
+            const uint64_t bm = __ballot(l32 < k && better(ls, li, xs, xi));
+            const int pos = __popcll(half ? (bm >> 32) : (bm & 0xffffffffull));
+            const float up_s = __shfl_up(ls, 1);
+            const int up_i = __shfl_up(li, 1);
+            if (active && l32 < k) {
+              if (l32 == pos) ls = xs, li = xi;
+              else if (l32 > pos) ls = up_s, li = up_i;
+            }
+            // candidates of this lane that no longer beat the k-th entry drop out
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (id[j] >= 0) {
+                const float ks2 = __shfl(ls, (lane & 32) + k - 1);
+                const int ki2 = __shfl(li, (lane & 32) + k - 1);
+                if (!better(v[j], id[j], ks2, ki2)) v[j] = -INFINITY, id[j] = -1;
+              }
+          }
+          if (l32 < k) {
+            run_s[row * KMAX + l32] = ls;
+            run_i[row * KMAX + l32] = li;
+          }
+          continue;
+        }
+      }
       float my_s = -INFINITY;
       int my_i = -1;
       for (int t = 0; t < k; ++t) {
@@ -330,8 +396,64 @@ __global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restr
   for (int e = tid; e < BM * k; e += 256) {
     const int row = e / k, t = e - row * k;
     if (m0 + row < Q) {
-      out_scores[(m0 + row) * k + t] = run_s[row * KMAX + t];
-      out_idx[(m0 + row) * k + t] = (int64_t)run_i[row * KMAX + t];
+      if (n_chunk > 0) {
+        const int64_t o = ((int64_t)blockIdx.y * Q + m0 + row) * k + t;
+        part_s[o] = run_s[row * KMAX + t];
+        part_i[o] = run_i[row * KMAX + t];
+      } else {
+        out_scores[(m0 + row) * k + t] = run_s[row * KMAX + t];
+        out_idx[(m0 + row) * k + t] = (int64_t)run_i[row * KMAX + t];
+      }
+    }
+  }
+}
+
+
+// split-N merge: one wave per query, the nsplit * k partial candidates (<= 256) sit 4 per lane, k rounds of wave
+// arg-max (ties -> smaller index) write the final list
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ part_s, const int* __restrict__ part_i,
+                                                         int nsplit, int64_t Q, int k, float* __restrict__ out_scores,
+                                                         int64_t* __restrict__ out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= Q) return;
+  const int total = nsplit * k;
+  float v[4];
+  int id[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int e = lane + 64 * c;
+    if (e < total) {
+      const int sp = e / k, t = e - sp * k;
+      v[c] = part_s[((int64_t)sp * Q + qi) * k + t];
+      id[c] = part_i[((int64_t)sp * Q + qi) * k + t];
+    } else {
+      v[c] = -INFINITY;
+      id[c] = -1;
+    }
+  }
+  for (int t = 0; t < k; ++t) {
+    float bs = v[0];
+    int bi = id[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+      if (better(v[c], id[c], bs, bi)) bs = v[c], bi = id[c];
+    float ws = bs;
+    int wi = bi;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(ws, off);
+      const int oi = __shfl_xor(wi, off);
+      if (better(os, oi, ws, wi)) ws = os, wi = oi;
+    }
+    if (lane == 0) {
+      out_scores[qi * k + t] = ws;
+      out_idx[qi * k + t] = (int64_t)wi;
+    }
+    if (wi >= 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (id[c] == wi) v[c] = -INFINITY, id[c] = -1;
     }
   }
 }
@@ -340,9 +462,26 @@ __global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restr
 
 using namespace rec;
 
-extern "C" int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
-                               int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
-                               int64_t* out_idx, void* stream) {
+// split-N plan: few query workgroups and many items -> spread the item range over nsplit workgroups per query tile
+static int topk_nsplit(int64_t Q, int64_t N, int k) {
+  const int64_t qblocks = (Q + topk::BM - 1) / topk::BM;
+  if (qblocks >= 128 || N < 2048) return 1;
+  int64_t ns = 512 / qblocks;              // aim at ~2 workgroups per CU
+  const int64_t by_items = N / 1024;       // at least 1024 items per split
+  if (ns > by_items) ns = by_items;
+  if (ns > 256 / k) ns = 256 / k;          // merge kernel: nsplit * k <= 256 candidates
+  return ns < 2 ? 1 : (int)ns;
+}
+
+extern "C" int64_t rec_topk_ip_workspace_bytes(int64_t Q, int64_t N, int32_t k) {
+  if (Q < 1 || N < 1 || k < 1 || k > topk::KMAX) return 0;
+  const int ns = topk_nsplit(Q, N, k);
+  return ns > 1 ? (int64_t)ns * Q * k * 8 : 0;
+}
+
+extern "C" int rec_topk_ip_ws_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
+                                  int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
+                                  int64_t* out_idx, void* workspace, void* stream) {
   const char* who = "rec_topk_ip_f32";
   REC_CHECK_ARG(Q >= 0 && N >= 0 && N <= 0x7fffffffLL, REC_ESHAPE, "%s: Q=%lld N=%lld", who, (long long)Q, (long long)N);
   REC_CHECK_ARG(d >= 1 && d <= topk::DMAX, REC_ESHAPE, "%s: d=%d (1..%d)", who, d, topk::DMAX);
@@ -357,19 +496,27 @@ extern "C" int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q
     const char* e = getenv("REC_TOPK_IMPL");  // "f32": fp32-MFMA kernel (A/B only)
     if (!(e && e[0] == 'f') && d <= 64) {  // d > 64: the bf16x3 form would spill (96 query + 64 staging VGPRs)
       const int vec_ok = (aligned16(queries) && aligned16(items) && q_stride % 4 == 0 && items_stride % 4 == 0) ? 1 : 0;
+      const int nsplit = workspace ? topk_nsplit(Q, N, k) : 1;
+      const int n_chunk = nsplit > 1 ? (int)(((N + nsplit - 1) / nsplit + 127) / 128 * 128) : 0;
+      float* part_s = static_cast<float*>(workspace);
+      int* part_i = nsplit > 1 ? reinterpret_cast<int*>(part_s + (int64_t)nsplit * Q * k) : nullptr;
 #define REC_TOPK_B3(KS_)                                                                                          \
   do {                                                                                                            \
     const size_t lds = (size_t)KS_ * 3 * 2 * 128 * 16 + (size_t)topk::BM * topk::KMAX * 8;                        \
     hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_ip_b3_kernel<KS_>),                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
     REC_CHECK_ARG(he == hipSuccess, REC_EHIP, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(he));         \
-    hipLaunchKernelGGL((topk_ip_b3_kernel<KS_>), dim3((unsigned)blocks), dim3(256), lds, st, queries, q_stride,   \
-                       items, items_stride, Q, (int)N, d, k, out_scores, out_idx, vec_ok);                        \
+    hipLaunchKernelGGL((topk_ip_b3_kernel<KS_>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), lds, st,    \
+                       queries, q_stride, items, items_stride, Q, (int)N, d, k, out_scores, out_idx, vec_ok,      \
+                       n_chunk, part_s, part_i);                                                                  \
   } while (0)
       if (d <= 16) REC_TOPK_B3(1);
       else if (d <= 32) REC_TOPK_B3(2);
       else REC_TOPK_B3(4);
 #undef REC_TOPK_B3
+      if (nsplit > 1)
+        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, part_s, part_i, nsplit, Q, k,
+                           out_scores, out_idx);
       REC_CHECK_LAUNCH(who);
       return REC_OK;
     }
@@ -384,4 +531,10 @@ extern "C" int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q
 #undef REC_TOPK
   REC_CHECK_LAUNCH(who);
   return REC_OK;
+}
+
+extern "C" int rec_topk_ip_f32(const float* queries, int64_t q_stride, int64_t Q, const float* items,
+                               int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
+                               int64_t* out_idx, void* stream) {
+  return rec_topk_ip_ws_f32(queries, q_stride, Q, items, items_stride, N, d, k, out_scores, out_idx, nullptr, stream);
 }

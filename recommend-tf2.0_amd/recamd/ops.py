@@ -616,8 +616,10 @@ def topk_inner_product(queries: torch.Tensor, items: torch.Tensor, k: int):
         raise ValueError("topk_inner_product: queries and items differ in dim")
     scores = torch.empty((Q, k), dtype=torch.float32, device=queries.device)
     idx = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
-    C.topk_ip_f32(queries.data_ptr(), queries.stride(0), Q, items.data_ptr() if N else 0, items.stride(0) if N else d,
-                  N, d, int(k), scores.data_ptr(), idx.data_ptr(), _stream())
+    nws = C.topk_ip_workspace_bytes(Q, N, int(k)) if (Q and N) else 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=queries.device) if nws else None
+    C.topk_ip_ws_f32(queries.data_ptr(), queries.stride(0), Q, items.data_ptr() if N else 0, items.stride(0) if N else d,
+                     N, d, int(k), scores.data_ptr(), idx.data_ptr(), _ptr(ws), _stream())
     return scores, idx
 
 

@@ -30,7 +30,8 @@ def check(D, I, eD, eI, q, items, tol=1e-5):
 
 
 @pytest.mark.parametrize("Q,N,d,k", [(1, 1, 8, 1), (5, 7, 8, 10), (130, 129, 32, 10), (257, 1000, 32, 10),
-                                     (64, 5000, 64, 32), (300, 300, 17, 5), (128, 2048, 128, 10)])
+                                     (64, 5000, 64, 32), (300, 300, 17, 5), (128, 2048, 128, 10),
+                                     (100, 20000, 32, 10), (6040, 3706, 32, 10), (7, 70000, 64, 32)])   # split-N path
 def test_topk_matches_oracle(dev, Q, N, d, k):
     from recamd import ops
     rng = np.random.default_rng(Q * 7 + N)
@@ -75,3 +76,15 @@ def test_empty_index_and_no_queries(dev):
     assert torch.isinf(D).all() and (D < 0).all() and (I == -1).all()
     D, I = ops.topk_inner_product(torch.empty((0, 8), device=dev), torch.randn(5, 8, device=dev), 4)
     assert D.shape == (0, 4) and I.shape == (0, 4)
+
+
+def test_split_n_ties_are_deterministic(dev):
+    """few queries, many items (split-N + merge kernel), integer-valued data with many equal scores"""
+    from recamd import ops
+    rng = np.random.default_rng(8)
+    q = rng.integers(-2, 3, size=(33, 16)).astype(np.float32)
+    items = rng.integers(-2, 3, size=(30000, 16)).astype(np.float32)
+    D, I = ops.topk_inner_product(torch.from_numpy(q).to(dev), torch.from_numpy(items).to(dev), 10)
+    eD, eI = ref.topk_inner_product(q, items, 10)
+    assert np.array_equal(D.cpu().numpy(), eD.astype(np.float32))
+    assert np.array_equal(I.cpu().numpy(), eI)
