@@ -465,7 +465,7 @@ using namespace rec;
 // split-N plan: few query workgroups and many items -> spread the item range over nsplit workgroups per query tile
 static int topk_nsplit(int64_t Q, int64_t N, int k) {
   const int64_t qblocks = (Q + topk::BM - 1) / topk::BM;
-  if (qblocks >= 128 || N < 2048) return 1;
+  if (qblocks >= 256 || N < 2048) return 1;
   int64_t ns = 512 / qblocks;              // aim at ~2 workgroups per CU
   const int64_t by_items = N / 1024;       // at least 1024 items per split
   if (ns > by_items) ns = by_items;
