@@ -289,33 +289,19 @@ __global__ __launch_bounds__(256) void pairdot_generic_kernel(const float* __res
 }
 
 int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const char* who);
-bool pairdot128_mfma_dispatch(const TableSet& ts, bool gather, bool has_dense, int ids_f32, int n,
-                              const void* ids, int64_t ids_stride, const float* xin,
-                              int64_t xin_stride, int64_t B, float* out, int64_t out_stride,
-                              int append_dense, int* oob, hipStream_t st);
-
-bool pairdot128_pipe_dispatch(const TableSet& ts, bool has_dense, int ids_f32, int n, const void* ids,
+// D = 128 fused form on the LDS-DMA ring + fp32 matrix cores (pairwise_dot_ring.hip): the default for the shapes it
+// covers (int32 ids, 16-B aligned padded output rows).  REC_PAIRDOT_IMPL=valu (read once) keeps the register-tiled
+// kernel of this file for A/B measurements.  Earlier variants that lost (LDS-transposed fp32 MFMA, software-pipelined
+// VALU, bf16x3 Gram) live under tools/exp/pairdot_variants/ and are not part of the library.
+bool pairdot128_ring_dispatch(const TableSet& ts, int F, bool has_dense, int ids_f32, const void* ids,
                               int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
                               int64_t out_stride, int append_dense, int* oob, hipStream_t st);
-bool pairdot128_gram_dispatch(const TableSet& ts, int F, bool has_dense, int ids_f32, const void* ids,
-                              int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
-                              int64_t out_stride, int append_dense, int* oob, hipStream_t st);
-// REC_PAIRDOT_IMPL=gram: bf16x3 matrix-core kernel (pairwise_dot_gram.hip)
-static bool use_gram() {
-  const char* e = getenv("REC_PAIRDOT_IMPL");
-  return e && e[0] == 'g';
-}
-static bool use_pipe() {
-  const char* e = getenv("REC_PAIRDOT_IMPL");
-  return e && e[0] == 'p';
-}
-
-// REC_PAIRDOT_IMPL=mfma selects the matrix-core variant for D = 128 (pairwise_dot_mfma.hip); it is
-// parity-green but currently latency-bound (247 us vs 231 us at 65 536 x 27 x 128, round 1), so
-// the register-tiled VALU kernel below stays the default.  A/B measurements only.
-static bool use_mfma() {
-  const char* e = getenv("REC_PAIRDOT_IMPL");
-  return e && e[0] == 'm';
+static bool use_ring() {
+  static const bool on = [] {
+    const char* e = getenv("REC_PAIRDOT_IMPL");
+    return !(e && e[0] == 'v');
+  }();
+  return on;
 }
 
 template <int LPR, int N, bool GATHER, bool HAS_DENSE, int IDS_F32>
@@ -360,12 +346,6 @@ extern "C" int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TableSet ts{};
   const bool vec_ok = D % 4 == 0 && aligned16(x);
-  if (vec_ok && D == 128 && use_mfma() &&
-      pairdot128_mfma_dispatch(ts, false, false, 0, n, nullptr, 0, x, (int64_t)n * D, B, out,
-                               out_stride, 0, nullptr, st)) {
-    REC_CHECK_LAUNCH(who);
-    return REC_OK;
-  }
 #define REC_TRY(LPR_, N_)                                                                         \
   if (vec_ok && D == (LPR_)*4 && n == (N_)) {                                                     \
     launch_pairdot<LPR_, N_, false, false, 0>(ts, nullptr, 0, x, (int64_t)n * D, B, out, out_stride, \
@@ -420,22 +400,9 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (D == 128 && use_gram() &&
-      pairdot128_gram_dispatch(ts, F, dense != nullptr, ids_dtype == REC_IDS_F32, ids, ids_stride, dense,
+  if (D == 128 && use_ring() &&
+      pairdot128_ring_dispatch(ts, F, dense != nullptr, ids_dtype == REC_IDS_F32, ids, ids_stride, dense,
                                dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
-    REC_CHECK_LAUNCH(who);
-    return REC_OK;
-  }
-  if (D == 128 && use_pipe() &&
-      pairdot128_pipe_dispatch(ts, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids, ids_stride, dense,
-                               dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
-    REC_CHECK_LAUNCH(who);
-    return REC_OK;
-  }
-  if (D == 128 && use_mfma() &&
-      pairdot128_mfma_dispatch(ts, true, dense != nullptr, ids_dtype == REC_IDS_F32, n, ids,
-                               ids_stride, dense, dense_stride, B, out, out_stride, append_dense,
-                               oob_flag, st)) {
     REC_CHECK_LAUNCH(who);
     return REC_OK;
   }

@@ -47,21 +47,20 @@ def test_golden_cross(dev):
     assert close(ops.cross_network(T(z["x"], dev), T(z["W"], dev), T(z["Bv"], dev)).cpu().numpy(), z["expected"])
 
 
-def test_golden_pairwise_dot_both_impls(dev, monkeypatch):
+def test_golden_pairwise_dot(dev):
     from recamd import ops
     z = load("pairwise_dot")
     assert close(ops.pairwise_dot(T(z["x"], dev)).cpu().numpy(), z["expected"])
-    monkeypatch.setenv("REC_PAIRDOT_IMPL", "mfma")
-    assert close(ops.pairwise_dot(T(z["x"], dev)).cpu().numpy(), z["expected"])
 
 
-def test_golden_dlrm_fused_both_impls(dev, monkeypatch):
+def test_golden_dlrm_fused_both_kernels(dev):
+    """int32 ids take the LDS-ring / fp32-MFMA kernel (pairwise_dot_ring.hip), float ids (the Keras
+    Embedding cast) the register-tiled kernel (pairwise_dot.hip): both against the same golden vectors."""
     from recamd import ops
     z = load("dlrm_dot")
     g = ops.TableGroup([T(z[f"table_{i}"], dev) for i in range(26)])
-    for impl in ("valu", "mfma"):
-        monkeypatch.setenv("REC_PAIRDOT_IMPL", impl)
-        out = ops.gather_pairwise_dot(g, T(z["ids"], dev), T(z["dense"], dev)).cpu().numpy()
+    for ids in (T(z["ids"], dev), T(z["ids"].astype(np.float32), dev)):
+        out = ops.gather_pairwise_dot(g, ids, T(z["dense"], dev)).cpu().numpy()
         assert close(out[:, :351], z["expected"])
         assert np.array_equal(out[:, 351:], z["dense"])
 
