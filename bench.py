@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): forward samples/sec of the DLRM sparse stage on synthetic
 Criteo-shaped batches — 65 536 samples x 26 sparse fields x dim 128, 1M rows per table — on N
-MI355X GPUs of one node.
+MI355X GPUs of one node.  `--workload` selects the other BASELINE configs for the same contract.
 
-A step = ONE pass of the hot path over one batch already resident in HBM: the fused
-gather + pairwise-dot launch (rec_gather_pairwise_dot_f32: ids -> 26 embedding rows + the bottom-MLP
-vector -> 351 dots ++ dense, (B, 479) out).  With --workload gather the step is the materialised
-gather+concat (rec_gather_concat_f32, (B, 3328) out) — the kernel the north-star roofline target is
-quoted on; its roofline is also reported beside the headline as "gather_roofline".
+  --workload dlrm_fused (default, configs[1]): ONE fused gather + pairwise-dot launch per step
+      (rec_gather_pairwise_dot_f32: ids -> 26 embedding rows + the bottom-MLP vector -> 351 dots ++ dense).
+  --workload gather : the materialised gather+concat (rec_gather_concat_f32) — the north-star roofline kernel;
+      also measured beside the headline as "gather_roofline".
+  --workload autoint (configs[2]) : AutoInt 39 fields x dim 16, 3 interacting layers, 2 heads, batch 4096.
+  --workload din     (configs[3]) : DIN history lookup + attention pooling, T <= 100, d = 192, batch 8192.
+  --workload sasrec  (configs[4]) : SASRec S = 200, d = 64, 1 block, 100 negatives, batch 8192 (global), forward.
 
-Multi-GPU (driver: torch.distributed.run, one rank per GPU): weak scaling, B samples per GPU.
---placement replicated (default): every GPU holds all 26 tables (13.3 GB of 288 GB) exactly like the
-  reference's MirroredStrategy mirrors its variables; the forward has no data-path collective.
---placement rowshard: tables row-sharded cyclically (owner = id % G) with an RCCL all-to-all of ids
-  out and rows back (recamd.dist.ShardedTables) — the xGMI-bound placement.
+A step = one pass of the hot path over one batch already resident in HBM.  Steps rotate over 8 distinct
+id batches, so no launch re-reads the rows of the launch before it out of the 256-MiB Infinity Cache.
+Untimed: a device spin-up (>= 0.3 s of steps: clocks and TLBs settle; the first ~100 ms after idle run up to
+25 % slower) and the W warm-up steps.  Timed: EXACTLY K steps between barrier + synchronize on both sides;
+`value` = units of all ranks / max-over-ranks wall time.  A second, separate pass brackets every launch with
+its own HIP events for the p10/p50/p90 in `launch_us`.
+
+Multi-GPU (driver: torch.distributed.run, one rank per GPU, RCCL): weak scaling, the same batch per GPU.
+  --placement replicated (default): every GPU holds all tables (13.3 GB of 288 GB), as the reference's
+      MirroredStrategy mirrors its variables (src/ctr/fm/train.py:43); the forward has no collective.
+  --placement rowshard: tables row-sharded cyclically (owner = id % G) behind the RCCL all-to-all pair
+      (recamd.dist.ShardedTables) — xGMI-bound for uniform ids.
+  With N > 1 the replicated line also carries a "rowshard" object measured in the same run (and vice versa
+  the placement is named in config.placement), so a scaling run reports both.
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,24 +40,23 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BF16_DENSE_PEAK_TF = 2500.0    # dense bf16 MFMA peak; a bf16x3 product costs 6 MFMAs -> 416.7 TF fp32-equivalent
+NB = 8                         # distinct id batches rotated over the steps
 
 
-def pmc_traffic(kernel_substr, a):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json:
-    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs of this same bench).  PMC
-    counters cannot be read from inside the timed run, so `traffic` is the latest committed
-    measurement for the SAME workload shape, or None."""
+def pmc_traffic(kernel_substr, cfg):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2
+    (gfx950 correction) + WRITE_SIZE, separate --pmc runs of this same bench).  PMC counters cannot be read from
+    inside the timed run, so `traffic` is the latest committed measurement for the SAME workload shape, or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    for f in reversed(files):
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))):
         try:
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
         c = d.get("config", {})
-        if (c.get("batch"), c.get("fields"), c.get("vocab"), c.get("dim"), c.get("ids")) != \
-                (a.batch, a.fields, a.vocab, a.dim, a.ids):
+        if any(c.get(k) != v for k, v in cfg.items()):
             continue
         for k, v in d.get("kernels", {}).items():
             if kernel_substr in k:
@@ -59,16 +69,189 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["dlrm_fused", "gather"], default="dlrm_fused")
+    ap.add_argument("--workload", choices=["dlrm_fused", "gather", "autoint", "din", "sasrec"], default="dlrm_fused")
     ap.add_argument("--placement", choices=["replicated", "rowshard"], default="replicated")
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
-    ap.add_argument("--batch", type=int, default=65536, help="samples per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--fields", type=int, default=26)
-    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--vocab", type=int, default=0, help="rows per table (0 = the BASELINE config's vocabulary)")
     ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=16384)
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (gather_roofline, rowshard)")
     return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------------
+# workloads: each returns a dict with  step(i), units (samples per step), bytes/flops the dominant kernel needs,
+# the roofline labels and the config description
+# --------------------------------------------------------------------------------------------------
+def make_ids(torch, dev, a, B, F, V, rank, shape=None):
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    out = []
+    for j in range(NB):
+        if a.ids == "uniform":
+            out.append(torch.randint(0, V, shape or (B, F), device=dev, dtype=torch.int32, generator=gen))
+        else:  # Zipf(1.05) clipped to V — Criteo-like skew
+            import numpy as np
+            z = np.random.default_rng(1 + rank + 1000 * j).zipf(1.05, size=shape or (B, F))
+            out.append(torch.from_numpy(((z - 1) % V).astype("int32")).to(dev))
+    return out
+
+
+def wl_dlrm(torch, dev, a, rank, world, fused=True):
+    from recamd import ops
+    B, F, V, D = a.batch or 65536, a.fields, a.vocab or 1_000_000, a.dim
+    n = F + 1
+    P = n * (n - 1) // 2
+    gen = torch.Generator(device=dev).manual_seed(0)
+    sharded = None
+    if a.placement == "replicated":
+        arena = torch.empty((F, V, D), dtype=torch.float32, device=dev)
+        arena.uniform_(-0.05, 0.05, generator=gen)  # keras 'random_uniform' (dlrm/model.py:34)
+        group = ops.TableGroup([arena[f] for f in range(F)])
+    else:
+        from recamd.dist import ShardedTables
+        rows_local = (V + world - 1 - rank) // world  # rows r with r % world == rank
+        arena = torch.empty((F, rows_local, D), dtype=torch.float32, device=dev)
+        arena.uniform_(-0.05, 0.05, generator=gen)
+        sharded = ShardedTables([arena[f] for f in range(F)], [V] * F, rank, world)
+        group = None
+    ids = make_ids(torch, dev, a, B, F, V, rank)
+    dense = torch.rand((B, D), device=dev, generator=gen)
+    # (B, 479) result with a 480-float (16-B aligned) row stride, as recamd.ops allocates it
+    out_fused = torch.empty((B, (P + D + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P + D]
+    out_gather = torch.empty((B, F * D), dtype=torch.float32, device=dev)
+
+    def step_fused(i):
+        if sharded is None:
+            ops.gather_pairwise_dot(group, ids[i % NB], dense, out=out_fused)
+        else:
+            sharded.lookup_pairwise_dot(ids[i % NB], dense, out=out_fused)
+
+    def step_gather(i):
+        if sharded is None:
+            ops.gather_concat(group, ids[i % NB], out=out_gather)
+        else:
+            sharded.lookup(ids[i % NB], out=out_gather)
+
+    bytes_fused = B * (F * D * 4 + F * 4 + D * 4 + (P + D) * 4)     # 15 844 B/sample at 26x128
+    bytes_gather = B * F * (2 * D * 4 + 4)                            # 26 728 B/sample at 26x128
+    shape_cfg = {"batch": B, "fields": F, "vocab": V, "dim": D, "ids": a.ids}
+    w = {
+        "units": B, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shape_cfg": shape_cfg,
+        "config": {"batch_per_gpu": B, "global_batch": B * world, "fields": F, "vocab_per_table": V, "dim": D,
+                   "ids": a.ids, "id_batches_rotated": NB},
+        "arena": arena, "ids": ids, "dense": dense, "sharded": sharded,
+    }
+    if fused:
+        w.update(step=step_fused, work=bytes_fused,
+                 kernel="rec::pairdot_ring_kernel<27, true, true, 2, 4, 0, 3> (LDS-DMA ring + fp32 MFMA: fused gather + "
+                        "pairwise dot)" if sharded is None else "row-sharded lookup (RCCL all-to-all pair) + pairwise dot",
+                 pmc_key="pairdot_ring_kernel",
+                 workload="DLRM 26 sparse x 1M vocab x dim 128, batch 65536/GPU: fused embedding gather + pairwise-dot "
+                          "(BASELINE configs[1])",
+                 side_gather=(step_gather, bytes_gather) if sharded is None else None)
+    else:
+        w.update(step=step_gather, work=bytes_gather, kernel="rec::gather_uniform_kernel<32, 0>",
+                 pmc_key="gather_uniform_kernel",
+                 workload="DLRM-shape materialised embedding gather+concat, batch 65536/GPU", side_gather=None)
+    return w
+
+
+def wl_autoint(torch, dev, a, rank, world):
+    from ctr.autoint.model import AutoInt
+    B, F, nd, D, V = a.batch or 4096, 26, 13, 16, a.vocab or 100_000
+    fc = [[{'feat': f'I{i}'} for i in range(nd)], [{'feat': f'C{i}', 'feat_num': V, 'embed_dim': D} for i in range(F)]]
+    m = AutoInt(fc, att_hidden_units=16, head_num=2, att_layer_num=3, use_res=True)
+    dense = torch.rand((B, nd), device=dev)
+    ids = make_ids(torch, dev, a, B, F, V, rank)
+    flop = 1_382_784  # SURVEY §8d per sample (QKV + QK^T + PV + residual projections of the 3 layers)
+
+    def step(i):
+        m([dense, ids[i % NB]])
+
+    return {"step": step, "units": B, "work": B * flop, "dtype": "f32 (bf16x3 MFMA: exact 3-term bf16 split, fp32 accumulate)",
+            "bound": "mfma", "peak": round(BF16_DENSE_PEAK_TF / 6, 1), "unit": "TFLOP/s",
+            "kernel": "rec::mha_ctr_b3_kernel (3 launches) + gather + final Dense: whole forward", "pmc_key": None,
+            "workload": "AutoInt 39 fields dim 16, 3-layer 2-head self-attn, batch 4096 (BASELINE configs[2])",
+            "config": {"batch_per_gpu": B, "global_batch": B * world, "fields": F + nd, "dim": D, "layers": 3, "heads": 2,
+                       "flop_per_sample": flop, "peak_note": "2.5 PFLOP/s dense bf16 / 6 MFMAs per fp32-equivalent product"},
+            "side_gather": None, "shape_cfg": {}}
+
+
+def wl_din(torch, dev, a, rank, world):
+    from recamd import ops
+    B, T, V = a.batch or 8192, 100, a.vocab or 1_000_000
+    d = 192
+    gen = torch.Generator(device=dev).manual_seed(4 + rank)
+    tabs = [torch.empty((V, 64), device=dev).uniform_(-0.05, 0.05, generator=gen) for _ in range(3)]
+    g = ops.TableGroup(tabs)
+    ids, real_slots = [], 0
+    for j in range(NB):
+        lens = torch.randint(1, T + 1, (B,), device=dev, generator=gen)
+        x = torch.randint(1, V, (B, T, 3), device=dev, dtype=torch.int32, generator=gen)
+        x[torch.arange(T, device=dev)[None, :] < (T - lens)[:, None]] = 0   # pre-padding with id 0 (pad_sequences)
+        ids.append(x)
+        real_slots += int(lens.sum().item())
+    q = torch.rand((B, d), device=dev, generator=gen)
+    W = torch.randn((4 * d, 1), device=dev, generator=gen) * 0.05
+    b = torch.zeros(1, device=dev)
+    out = torch.empty((B, d), device=dev)
+
+    def step(i):
+        ops.gather_din_attention_pool(q, g, ids[i % NB], None, W, b, 'sigmoid', mask_from_ids=True, out=out)
+
+    # bytes the kernel needs: ids of all T slots, rows of the REAL slots only (padded slots carry softmax weight
+    # exactly 0 and are not fetched), q in, pooled row out
+    need = B * (T * 3 * 4 + 2 * d * 4) + (real_slots / NB) * d * 4
+    return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "rec::din_pool_gather_kernel (fused history lookup + attention pooling)", "pmc_key": None,
+            "workload": "DIN var-len user history (max 100) attention pooling, batch 8192 (BASELINE configs[3])",
+            "config": {"batch_per_gpu": B, "global_batch": B * world, "maxlen": T, "d": d, "vocab_per_table": V,
+                       "mean_real_slots": round(real_slots / NB / B, 2),
+                       "bytes_note": "rows of real (non-pad) history slots only + all ids + q + out"},
+            "side_gather": None, "shape_cfg": {}}
+
+
+def wl_sasrec(torch, dev, a, rank, world):
+    from match.sasrec.model import SASRec
+    Bg = a.batch * world if a.batch else 8192
+    B = max(1, Bg // world)                       # config 5: global batch 8192, 1024 per GPU at 8 GPUs
+    S, n, V, d = 200, 100, a.vocab or 10_000_000, 64
+    uf = [{'feat': 'seq_item', 'feat_num': V, 'feat_len': S, 'embed_dim': d},
+          {'feat': 'pos_item', 'feat_num': V, 'feat_len': 1, 'embed_dim': d},
+          {'feat': 'neg_item', 'feat_num': V, 'feat_len': n, 'embed_dim': d}]
+    kw = {}
+    if a.placement == "rowshard":
+        kw = {"sharded": (rank, world)}
+    m = SASRec(uf, [], blocks=1, num_heads=1, att_hidden_unit=d, ffn_hidden_unit=128, seq_len=S, neg_len=n, **kw)
+    gen = torch.Generator(device=dev).manual_seed(5 + rank)
+    batches, real = [], 0
+    for j in range(NB):
+        lens = torch.randint(1, S + 1, (B,), device=dev, generator=gen)
+        seq = torch.randint(1, V, (B, S), device=dev, dtype=torch.int32, generator=gen)
+        seq[torch.arange(S, device=dev)[None, :] < (S - lens)[:, None]] = 0
+        pos = torch.randint(1, V, (B, 1), device=dev, dtype=torch.int32, generator=gen)
+        neg = torch.randint(1, V, (B, n), device=dev, dtype=torch.int32, generator=gen)
+        batches.append([seq, pos, neg])
+        real += int(lens.sum().item())
+
+    def step(i):
+        m(batches[i % NB])
+
+    need = B * ((S + 1 + n) * 4 + (1 + n) * d * 4 + (1 + n) * 4) + (real / NB) * d * 4
+    return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "SASRec forward, exact last-row form (rec_gather_mha_fewq_f32 + FFN/LN on one row + "
+                      "rec_gather_dot_scores_f32): item rows read once", "pmc_key": None,
+            "workload": "SASRec seq 200 dim 64, 10M-item tables, 1 block, 100 negatives, global batch 8192 "
+                        "(BASELINE configs[4])" + (", tables row-sharded over the ranks (RCCL all-to-all)"
+                                                   if a.placement == "rowshard" else ""),
+            "config": {"batch_per_gpu": B, "global_batch": B * world, "seq_len": S, "neg_len": n, "d": d,
+                       "vocab_per_table": V, "mean_real_positions": round(real / NB / B, 2),
+                       "bytes_note": "item rows of real positions + pos/neg rows + ids + logits"},
+            "side_gather": None, "shape_cfg": {}}
 
 
 def main():
@@ -99,114 +282,134 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from recamd import ops
-
-    B, F, V, D = a.batch, a.fields, a.vocab, a.dim
-    n = F + 1
-    P = n * (n - 1) // 2
-
-    # ---- synthetic data, generated on device (there is no dataset; BASELINE config 2) ----------
-    gen = torch.Generator(device=dev).manual_seed(0)
-    if a.placement == "replicated":
-        arena = torch.empty((F, V, D), dtype=torch.float32, device=dev)
-        arena.uniform_(-0.05, 0.05, generator=gen)  # keras 'random_uniform' (dlrm/model.py:34)
-        group = ops.TableGroup([arena[f] for f in range(F)])
-        sharded = None
-    else:
-        from recamd.dist import ShardedTables
-        rows_local = (V + world - 1 - rank) // world  # rows r with r % world == rank
-        arena = torch.empty((F, rows_local, D), dtype=torch.float32, device=dev)
-        arena.uniform_(-0.05, 0.05, generator=gen)
-        sharded = ShardedTables([arena[f] for f in range(F)], [V] * F, rank, world)
-        group = None
-    gen_i = torch.Generator(device=dev).manual_seed(1 + rank)
-    if a.ids == "uniform":
-        ids = torch.randint(0, V, (B, F), device=dev, dtype=torch.int32, generator=gen_i)
-    else:  # Zipf(1.05) clipped to V — Criteo-like skew
-        import numpy as np
-        z = np.random.default_rng(1 + rank).zipf(1.05, size=(B, F))
-        ids = torch.from_numpy(((z - 1) % V).astype("int32")).to(dev)
-    dense = torch.rand((B, D), device=dev, generator=gen_i)
-    # (B, 479) result with a 480-float (16-B aligned) row stride, as recamd.ops allocates it
-    out_fused = torch.empty((B, (P + D + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P + D]
-    out_gather = torch.empty((B, F * D), dtype=torch.float32, device=dev)
-
-    def step_fused():
-        if sharded is None:
-            ops.gather_pairwise_dot(group, ids, dense, out=out_fused)
-        else:
-            emb = sharded.lookup(ids)  # (B, F*D) through the all-to-all pair
-            x = torch.cat([emb.view(B, F, D), dense[:, None, :]], dim=1)
-            ops.pairwise_dot(x, out=out_fused[:, :P])
-            out_fused[:, P:] = dense
-
-    def step_gather():
-        if sharded is None:
-            ops.gather_concat(group, ids, out=out_gather)
-        else:
-            sharded.lookup(ids, out=out_gather)
-
-    step = step_fused if a.workload == "dlrm_fused" else step_gather
-    bytes_fused = B * (F * D * 4 + F * 4 + D * 4 + (P + D) * 4)     # 15 844 B/sample at 26x128
-    bytes_gather = B * F * (2 * D * 4 + 4)                            # 26 728 B/sample at 26x128
-    bytes_step = bytes_fused if a.workload == "dlrm_fused" else bytes_gather
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed(fn, steps):
-        """barrier + sync, `steps` launches bracketed by HIP events on the launch stream, sync +
-        barrier; returns (wall seconds, mean device ms per launch from the events)."""
+    def build(wl, placement):
+        a.placement = placement
+        if wl == "dlrm_fused":
+            return wl_dlrm(torch, dev, a, rank, world, fused=True)
+        if wl == "gather":
+            return wl_dlrm(torch, dev, a, rank, world, fused=False)
+        if wl == "autoint":
+            return wl_autoint(torch, dev, a, rank, world)
+        if wl == "din":
+            return wl_din(torch, dev, a, rank, world)
+        return wl_sasrec(torch, dev, a, rank, world)
+
+    def spin(step, seconds):
+        """untimed: run steps for `seconds` of wall time so clocks / TLBs are in their steady state"""
+        t0, i = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(16):
+                step(i)
+                i += 1
+            torch.cuda.synchronize()
+
+    def timed(step, steps):
+        """barrier + sync, `steps` launches bracketed by HIP events on the launch stream, sync + barrier;
+        returns (wall seconds, mean device ms per step from the events)."""
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(steps):
-            fn()
+        for i in range(steps):
+            step(i)
         e1.record()
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
         return t1 - t0, e0.elapsed_time(e1) / steps
 
-    for _ in range(a.warmup):
-        step()
-    wall, dev_ms = timed(step, a.steps)
-    if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
+    def per_launch(step, steps):
+        """separate pass: every step between its own pair of events -> sorted per-step microseconds"""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for i in range(steps):
+            step(i)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(steps)]
 
-    # the north-star roofline kernel (materialised gather) measured in the same run, rank-local
+    def stats(us):
+        s = sorted(us)
+        rest = us[1:] if len(us) > 1 else us
+        return {"p10": round(s[len(s) // 10], 1), "p50": round(s[len(s) // 2], 1), "p90": round(s[(9 * len(s)) // 10], 1),
+                "first": round(us[0], 1), "mean_without_first": round(sum(rest) / len(rest), 1), "n": len(us)}
+
+    def measure(w):
+        spin(w["step"], a.spinup)
+        for i in range(a.warmup):
+            w["step"](i)
+        wall, dev_ms = timed(w["step"], a.steps)
+        if world > 1:
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+        launch = stats(per_launch(w["step"], min(a.steps, 200)))
+        return wall, dev_ms, launch
+
+    w = build(a.workload, a.placement)
+    head = {k: w[k] for k in ("units", "dtype", "workload", "config")}
+    wall, dev_ms, launch = measure(w)
+
+    def roofline(w, dev_ms, launch):
+        scale = 1e9 if w["unit"] == "GB/s" else 1e12
+        ach = w["work"] / (dev_ms * 1e-3) / scale
+        ach50 = w["work"] / (launch["p50"] * 1e-6) / scale
+        traffic, src = (pmc_traffic(w["pmc_key"], w["shape_cfg"]) if w.get("pmc_key") and w.get("sharded") is None
+                        else (None, None))
+        key = "algorithmic_bytes_per_launch" if w["unit"] == "GB/s" else "flop_per_step"
+        return {"kernel": w["kernel"], "bound": w["bound"], "achieved": round(ach, 1), "peak": w["peak"],
+                "unit": w["unit"], "frac": round(ach / w["peak"], 4), "traffic": traffic, "traffic_source": src,
+                key: int(w["work"]), "ms_per_launch": round(dev_ms, 4), "launch_us": launch,
+                "frac_p50": round(ach50 / w["peak"], 4)}
+
+    roof = roofline(w, dev_ms, launch)
+
+    # side measurements in the same run: the north-star gather kernel; at N > 1 the other placement
     gather_roof = None
-    if a.workload == "dlrm_fused" and sharded is None:
-        for _ in range(5):
-            step_gather()
-        _, g_ms = timed(step_gather, max(20, a.steps // 4))
-        ach = bytes_gather / (g_ms * 1e-3) / 1e9
-        g_traffic, g_src = pmc_traffic("gather_uniform_kernel", a)
-        gather_roof = {"kernel": "gather_uniform_kernel", "bound": "hbm", "achieved": round(ach, 1),
+    if not a.no_side and w.get("side_gather"):
+        sg, sbytes = w["side_gather"]
+        spin(sg, 0.1)
+        _, g_ms = timed(sg, max(20, a.steps // 4))
+        g_launch = stats(per_launch(sg, max(20, a.steps // 4)))
+        ach = sbytes / (g_ms * 1e-3) / 1e9
+        g_traffic, g_src = pmc_traffic("gather_uniform_kernel", w["shape_cfg"])
+        gather_roof = {"kernel": "rec::gather_uniform_kernel<32, 0>", "bound": "hbm", "achieved": round(ach, 1),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                       "traffic": g_traffic, "traffic_source": g_src,
-                       "algorithmic_bytes_per_launch": bytes_gather, "ms_per_launch": round(g_ms, 4),
-                       "samples_per_s": round(B / (g_ms * 1e-3), 1)}
-
+                       "frac_p50": round(sbytes / (g_launch["p50"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": g_traffic, "traffic_source": g_src, "algorithmic_bytes_per_launch": sbytes,
+                       "ms_per_launch": round(g_ms, 4), "launch_us": g_launch,
+                       "samples_per_s": round(w["units"] / (g_ms * 1e-3), 1)}
     cpu_base = None
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
-        cpu_base = cpu_baseline(a, arena, ids, dense, F, V, D)
+    if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.workload in ("dlrm_fused", "gather"):
+        cpu_base = cpu_baseline(a, w)
+
+    other = None
+    if not a.no_side and world > 1 and a.workload in ("dlrm_fused", "gather", "sasrec"):
+        first_placement = a.placement
+        alt = "rowshard" if first_placement == "replicated" else "replicated"
+        try:
+            del w
+            torch.cuda.empty_cache()
+            w2 = build(a.workload, alt)
+            wall2, dev2, launch2 = measure(w2)
+            other = {"placement": alt, "value": round(world * w2["units"] * a.steps / wall2, 1), "unit": "samples/s",
+                     "ms_per_step": round(wall2 / a.steps * 1e3, 4), "launch_us": launch2,
+                     "exchange": w2["sharded"].describe() if w2.get("sharded") is not None else None}
+        except Exception as e:  # noqa: BLE001  (a failing side measurement must not cost the headline line)
+            other = {"placement": alt, "error": f"{type(e).__name__}: {e}"[:300]}
+        a.placement = first_placement
 
     if rank == 0:
-        achieved = bytes_step / (dev_ms * 1e-3) / 1e9
-        kern = ("rec::pairdot_kernel<32, 27, true, true, 0, true> (fused gather + pairwise dot, staged stores)"
-                if a.workload == "dlrm_fused" else "rec::gather_uniform_kernel<32, 0>")
-        traffic, traffic_src = (pmc_traffic("pairdot_kernel" if a.workload == "dlrm_fused" else
-                                            "gather_uniform_kernel", a) if sharded is None else (None, None))
         res = {
             "metric": "forward samples/sec, Criteo-shape 65536x26 sparse x dim128",
-            "value": round(world * B * a.steps / wall, 1),
+            "value": round(world * head["units"] * a.steps / wall, 1),
             "unit": "samples/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -215,20 +418,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": head["dtype"],
             "data": "synthetic",
-            "config": {"workload": ("DLRM 26 sparse x 1M vocab x dim 128, batch 65536/GPU: fused embedding gather + "
-                                    "pairwise-dot (BASELINE configs[1])" if a.workload == "dlrm_fused" else
-                                    "DLRM-shape materialised embedding gather+concat, batch 65536/GPU"),
-                       "step": a.workload, "batch_per_gpu": B, "global_batch": B * world, "fields": F,
-                       "vocab_per_table": V, "dim": D, "ids": a.ids, "placement": a.placement,
-                       "parallelism": f"dp{world}"},
-            "roofline": {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_step, "ms_per_launch": round(dev_ms, 4)},
+            "config": dict({"workload": head["workload"], "step": a.workload, "placement": a.placement,
+                            "parallelism": f"dp{world}", "spinup_s": a.spinup}, **head["config"]),
+            "roofline": roof,
         }
         if gather_roof is not None:
             res["gather_roofline"] = gather_roof
+        if other is not None:
+            res[other["placement"]] = other
         if cpu_base is not None:
             res["cpu_baseline"] = cpu_base
         print(json.dumps(res), flush=True)
@@ -236,17 +435,19 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, arena, ids, dense, F, V, D):
-    """The CPU restatement (oracle/oracle_c.c, OpenMP, kind "port") of the same workload on the
-    box's host cores: the reference's own CPU path cannot run (TensorFlow is not installed, the
-    reference never travels to the GPU box).  Bounded sample: the first --cpu-samples samples of
-    the same batch against the same 13.3 GB tables copied to host memory."""
+def cpu_baseline(a, w):
+    """The CPU restatement (oracle/oracle_c.c, OpenMP, kind "port") of the same workload on the box's host cores:
+    the reference's own CPU path cannot run (TensorFlow is not installed, the reference never travels to the GPU
+    box).  Bounded sample: the first --cpu-samples samples of the first id batch against the same 13.3 GB tables
+    copied to host memory, repeated until the time budget is spent."""
     import numpy as np
     try:
         from oracle import c_oracle
         c_oracle.load()
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "samples/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    arena, ids, dense = w["arena"], w["ids"][0], w["dense"]
+    F, D = arena.shape[0], arena.shape[2]
     Bc = min(a.cpu_samples, ids.shape[0])
     host = arena.cpu().numpy()  # (F, V, D) fp32
     tables = [host[f] for f in range(F)]
@@ -270,8 +471,10 @@ def cpu_baseline(a, arena, ids, dense, F, V, D):
             break
     return {"value": round(Bc * reps / el, 1), "unit": "samples/s", "cores": c_oracle.num_threads(),
             "kind": "port",
-            "sample": f"first {Bc} samples of the same batch x {reps} passes ({el:.1f} s), same 26x1Mx128 tables "
-                      f"in host memory, C/OpenMP restatement of gather+concat+pairwise-dot (TensorFlow unavailable)"}
+            "sample": f"the first {Bc} samples of one id batch, the SAME slice replayed {reps} times ({el:.1f} s; its "
+                      f"{Bc * F * D * 4 / 1e6:.0f} MB of looked-up rows stay cache-warm on the host after the first pass), "
+                      f"same 26x1Mx128 tables in host memory, C/OpenMP restatement of gather+concat+pairwise-dot "
+                      f"(TensorFlow unavailable)"}
 
 
 if __name__ == "__main__":

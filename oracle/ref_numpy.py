@@ -570,10 +570,20 @@ def ncf_forward(user, pos, neg, user_table, item_table, neg_table, dnn_layers, f
 # --------------------------------------------------------------------------------------------
 def binary_crossentropy(y_true, y_pred, eps=1e-7, dtype=np.float64):
     """tf.keras.losses.binary_crossentropy on probabilities, averaged over all samples
-    (src/ctr/deep_fm/train.py:50): p clipped to [eps, 1-eps]."""
+    (src/ctr/deep_fm/train.py:50).  tf.keras.backend.binary_crossentropy (from_logits=False): the prediction is
+    clipped to [eps, 1-eps] and eps is added again INSIDE both logs: -(y log(p + eps) + (1-y) log(1 - p + eps)).
+    (Graph-mode TF may route a Sigmoid-op output through sigmoid_cross_entropy_with_logits instead — no clip;
+    `binary_crossentropy_from_logits` restates that branch.)  Parity unpinned: no fixtures, TF not importable."""
     y = np.asarray(y_true, dtype).reshape(-1)
     p = np.clip(np.asarray(y_pred, dtype).reshape(-1), eps, 1.0 - eps)
-    return float(np.mean(-(y * np.log(p) + (1.0 - y) * np.log(1.0 - p))))
+    return float(np.mean(-(y * np.log(p + eps) + (1.0 - y) * np.log(1.0 - p + eps))))
+
+
+def binary_crossentropy_from_logits(y_true, logits, dtype=np.float64):
+    """tf.nn.sigmoid_cross_entropy_with_logits averaged: max(x,0) - x z + log(1 + exp(-|x|))."""
+    z = np.asarray(y_true, dtype).reshape(-1)
+    x = np.asarray(logits, dtype).reshape(-1)
+    return float(np.mean(np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))))
 
 
 def keras_auc(y_true, y_pred, num_thresholds=200):

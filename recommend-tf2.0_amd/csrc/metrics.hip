@@ -28,7 +28,12 @@ __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restric
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float pc = fminf(fmaxf(p[i], 1e-7f), 1.0f - 1e-7f);
     const float yy = y[i];
-    acc += (double)(-(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc)));
+    // Keras backend.binary_crossentropy on probabilities: clip to [eps, 1-eps], THEN log(p + eps) / log(1 - p + eps)
+    // (tf.keras.backend: `bce = target * log(output + epsilon()); bce += (1 - target) * log(1 - output + epsilon())`).
+    // In graph mode TF may instead recover the logits of a Sigmoid-op output and call
+    // sigmoid_cross_entropy_with_logits (no clip): the two differ only on saturated predictions.  Parity unpinned
+    // (no fixtures, TensorFlow not importable).
+    acc += (double)(-(yy * logf(pc + 1e-7f) + (1.0f - yy) * logf(1.0f - pc + 1e-7f)));
   }
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;

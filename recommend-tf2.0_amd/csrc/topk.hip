@@ -346,14 +346,16 @@ __global__ __launch_bounds__(256, 2) void topk_ip_b3_kernel(const float* __restr
               if (l32 == pos) ls = xs, li = xi;
               else if (l32 > pos) ls = up_s, li = up_i;
             }
-            // candidates of this lane that no longer beat the k-th entry drop out
+            // candidates of this lane that no longer beat the k-th entry drop out.  The k-th entry is read in
+            // wave-uniform control flow: a shuffle from an EXEC-disabled source lane returns 0, which used to drop
+            // true candidates whose score is <= 0 (lane k-1 often holds no candidate itself).
+            {
+              const float ks2 = __shfl(ls, (lane & 32) + k - 1);
+              const int ki2 = __shfl(li, (lane & 32) + k - 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (id[j] >= 0) {
-                const float ks2 = __shfl(ls, (lane & 32) + k - 1);
-                const int ki2 = __shfl(li, (lane & 32) + k - 1);
-                if (!better(v[j], id[j], ks2, ki2)) v[j] = -INFINITY, id[j] = -1;
-              }
+              for (int j = 0; j < 4; ++j)
+                if (id[j] >= 0 && !better(v[j], id[j], ks2, ki2)) v[j] = -INFINITY, id[j] = -1;
+            }
           }
           if (l32 < k) {
             run_s[row * KMAX + l32] = ls;
@@ -483,7 +485,8 @@ extern "C" int rec_topk_ip_ws_f32(const float* queries, int64_t q_stride, int64_
                                   int64_t items_stride, int64_t N, int32_t d, int32_t k, float* out_scores,
                                   int64_t* out_idx, void* workspace, void* stream) {
   const char* who = "rec_topk_ip_f32";
-  REC_CHECK_ARG(Q >= 0 && N >= 0 && N <= 0x7fffffffLL, REC_ESHAPE, "%s: Q=%lld N=%lld", who, (long long)Q, (long long)N);
+  // tile offsets (n0 + BN, n_begin + n_chunk, n0 + 32 j + lane) are int arithmetic: keep a tile of headroom below 2^31
+  REC_CHECK_ARG(Q >= 0 && N >= 0 && N <= 0x7fffffffLL - 256, REC_ESHAPE, "%s: Q=%lld N=%lld (N must be <= 2^31 - 257)", who, (long long)Q, (long long)N);
   REC_CHECK_ARG(d >= 1 && d <= topk::DMAX, REC_ESHAPE, "%s: d=%d (1..%d)", who, d, topk::DMAX);
   REC_CHECK_ARG(k >= 1 && k <= topk::KMAX, REC_ESHAPE, "%s: k=%d (1..%d)", who, k, topk::KMAX);
   REC_CHECK_ARG(q_stride >= d && items_stride >= d, REC_ESHAPE, "%s: strides smaller than d", who);

@@ -65,7 +65,19 @@ class Layer:
         self._w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._children: "OrderedDict[str, Layer]" = OrderedDict()
         self._device = device
-        self._version = 0  # bumped by set_weights (invalidates folded/cached weights)
+        self._v = 0  # bumped by set_weights (invalidates folded/cached weights)
+
+    @property
+    def _version(self) -> int:
+        """cache key of everything derived from this layer's weights: set_weights bumps the layer's own counter,
+        the optimiser kernels (raw-pointer writers) bump ops.weight_generation()"""
+        from . import ops
+        return self._v + ops.weight_generation()
+
+    @_version.setter
+    def _version(self, value: int) -> None:
+        from . import ops
+        self._v = value - ops.weight_generation()
 
     @property
     def device(self):

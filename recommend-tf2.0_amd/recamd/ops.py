@@ -541,7 +541,7 @@ def dice(x: torch.Tensor, alpha: torch.Tensor, mean=None, var=None, eps: float =
 
 
 def gather_din_attention_pool(q, group: TableGroup, ids, mask, W, bias, act="sigmoid", alpha=None,
-                              mask_from_ids=False, oob_flag=None) -> torch.Tensor:
+                              mask_from_ids=False, oob_flag=None, out=None) -> torch.Tensor:
     """Fused history gather + DIN pooling: ids (B, T, n_tab) index `group`'s tables (one shared dim);
     k = v = the gathered (B, T, n_tab*Dt) history, never materialised.  mask: (B,T) float tensor, or
     None with mask_from_ids=True (slot real iff ids[b,t,0] != 0), or None (uniform, modules.py:164-165)."""
@@ -556,7 +556,10 @@ def gather_din_attention_pool(q, group: TableGroup, ids, mask, W, bias, act="sig
     if mask is not None:
         mask = _chk(mask, "mask").contiguous()
     W = _chk(W, "W").reshape(-1)
-    out = torch.empty((B, d), dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty((B, d), dtype=torch.float32, device=q.device)
+    elif _chk(out, "out").shape != (B, d) or not out.is_contiguous():
+        raise ValueError("out: expected contiguous (B, n_tab*Dt)")
     C.gather_din_attn_pool_f32(q.data_ptr(), group.descs, ids.data_ptr(), _ids_dtype(ids), _ptr(mask),
                                1 if mask_from_ids else 0, W.data_ptr(), _chk(bias, "bias").data_ptr(), _ptr(alpha),
                                _act_id(act), B, T, out.data_ptr(), _ptr(oob_flag), _stream())
@@ -595,6 +598,22 @@ def embedding_grad(grad_group: TableGroup, ids: torch.Tensor, dy: torch.Tensor) 
                              dy.data_ptr(), dy.stride(0), B, _stream())
 
 
+# Raw-pointer writers (the optimiser kernels) change weights behind torch's back.  Every cache of derived weights
+# must notice: `note_weights_written` bumps torch's own version counter of the tensor (the pre-split Dense cache keys
+# on it) and a process-wide generation that recamd.nn.Layer._version includes (folded BatchNorm, fused QKV, ...).
+_weight_generation = [0]
+
+
+def weight_generation() -> int:
+    return _weight_generation[0]
+
+
+def note_weights_written(*tensors: torch.Tensor) -> None:
+    _weight_generation[0] += 1
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
+
+
 def adam_step(var: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor, step: int, lr: float = 1e-3,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7, l2: float = 0.0) -> None:
     """In-place dense Keras-Adam update (TF2 defaults) with the embeddings' l2(c) regulariser gradient 2 c var."""
@@ -604,6 +623,7 @@ def adam_step(var: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.T
             raise ValueError(f"{nm}: must be contiguous and match var")
     C.adam_f32(var.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), var.numel(), float(lr), float(beta1),
                float(beta2), float(eps), int(step), float(l2), _stream())
+    note_weights_written(var, m, v)
 
 
 def topk_inner_product(queries: torch.Tensor, items: torch.Tensor, k: int):

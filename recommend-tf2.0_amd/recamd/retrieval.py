@@ -12,7 +12,13 @@ from .nn import default_device, to_device_f32
 
 class IndexFlatIP:
     """Exact inner-product index.  `add` appends vectors (kept in HBM), `search` returns (D, I) as numpy arrays:
-    D (Q, k) scores descending, I (Q, k) int64 positions in insertion order (-1 where fewer than k vectors)."""
+    D (Q, k) scores descending, I (Q, k) int64 positions in insertion order.  Where fewer than k vectors exist the
+    label is -1 and the score is -FLT_MAX (-3.4028235e38), faiss' heap-neutral value for IndexFlatIP (the kernel
+    itself pads with -inf: `recamd.ops.topk_inner_product`).  Limits of the kernel (it raises beyond them; faiss does
+    not have them): k <= 32, d <= 128, ntotal <= 2^31 - 257.  NaN scores are never selected, and a +-inf component in
+    a vector turns its scores into NaN for d <= 64 (bf16x3 split, csrc/bf16x3.h).  faiss is not importable here:
+    parity with it is unpinned (ties resolve to the smaller index, which is also what faiss' heap yields for
+    insertion-ordered equal scores in practice, not by contract)."""
 
     def __init__(self, d: int, device=None):
         self.d = int(d)
@@ -37,4 +43,6 @@ class IndexFlatIP:
         if x.ndim != 2 or x.shape[1] != self.d:
             raise ValueError(f"search: expected (n, {self.d}), got {tuple(x.shape)}")
         D, I = ops.topk_inner_product(x.contiguous(), self._items, k)
-        return D.cpu().numpy(), I.cpu().numpy()
+        D, I = D.cpu().numpy(), I.cpu().numpy()
+        D[I < 0] = np.float32(-3.4028235e38)
+        return D, I

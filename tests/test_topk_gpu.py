@@ -42,6 +42,46 @@ def test_topk_matches_oracle(dev, Q, N, d, k):
     check(D.cpu().numpy(), I.cpu().numpy(), eD, eI, q, items)
 
 
+@pytest.mark.parametrize("N", [3, 200, 5000, 70000])
+@pytest.mark.parametrize("d", [8, 64])
+def test_topk_all_negative_scores(dev, N, d):
+    """Every candidate scores < 0 (queries > 0, items < 0): the insertion path must compare against the live k-th
+    entry, not against the (0.0, 0) a shuffle from an EXEC-disabled lane returns (round-1 ADVICE, topk.hip:351)."""
+    from recamd import ops
+    rng = np.random.default_rng(N + d)
+    q = rng.uniform(0.1, 1.0, size=(33, d)).astype(np.float32)
+    items = -rng.uniform(0.1, 1.0, size=(N, d)).astype(np.float32)
+    k = 10
+    D, I = ops.topk_inner_product(torch.from_numpy(q).to(dev), torch.from_numpy(items).to(dev), k)
+    eD, eI = ref.topk_inner_product(q, items, k)
+    check(D.cpu().numpy(), I.cpu().numpy(), eD, eI, q, items)
+
+
+def test_topk_tiny_negative_kat(dev):
+    """Q=1, N=3, scores -1, -2, -3 -> indices [0, 1, 2], then -1 padding."""
+    from recamd import ops
+    q = np.ones((1, 8), np.float32)
+    items = np.zeros((3, 8), np.float32)
+    items[:, 0] = [-1, -2, -3]
+    D, I = ops.topk_inner_product(torch.from_numpy(q).to(dev), torch.from_numpy(items).to(dev), 10)
+    I = I.cpu().numpy()
+    D = D.cpu().numpy()
+    assert I[0, :3].tolist() == [0, 1, 2] and np.all(I[0, 3:] == -1)
+    assert D[0, :3].tolist() == [-1.0, -2.0, -3.0]
+
+
+def test_topk_zero_score_ties(dev):
+    """all scores exactly 0 (orthogonal vectors): ties resolve to the smallest indices, in order."""
+    from recamd import ops
+    q = np.zeros((5, 16), np.float32)
+    q[:, 0] = 1
+    items = np.zeros((300, 16), np.float32)
+    items[:, 1] = np.arange(300)
+    D, I = ops.topk_inner_product(torch.from_numpy(q).to(dev), torch.from_numpy(items).to(dev), 10)
+    assert np.array_equal(I.cpu().numpy(), np.tile(np.arange(10), (5, 1)))
+    assert np.array_equal(D.cpu().numpy(), np.zeros((5, 10), np.float32))
+
+
 def test_ties_order_by_index(dev):
     """integer-valued vectors: exact scores with many ties -> smaller index first, bit-exact scores."""
     from recamd import ops
