@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=16384)
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (gather_roofline, rowshard)")
+    ap.add_argument("--side-timeout", type=float, default=240.0, help="watchdog of the N>1 side placement measurement (s)")
     return ap.parse_args()
 
 
@@ -127,14 +128,16 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
     def step_fused(i):
         if sharded is None:
             ops.gather_pairwise_dot(group, ids[i % NB], dense, out=out_fused)
-        else:
+        else:  # the plan (dedup, bucketing, count exchange) of the NEXT batch is issued behind this batch's lookup
             sharded.lookup_pairwise_dot(ids[i % NB], dense, out=out_fused)
+            sharded.prefetch(ids[(i + 1) % NB])
 
     def step_gather(i):
         if sharded is None:
             ops.gather_concat(group, ids[i % NB], out=out_gather)
         else:
             sharded.lookup(ids[i % NB], out=out_gather)
+            sharded.prefetch(ids[(i + 1) % NB])
 
     bytes_fused = B * (F * D * 4 + F * 4 + D * 4 + (P + D) * 4)     # 15 844 B/sample at 26x128
     bytes_gather = B * F * (2 * D * 4 + 4)                            # 26 728 B/sample at 26x128
@@ -390,22 +393,7 @@ def main():
     if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.workload in ("dlrm_fused", "gather"):
         cpu_base = cpu_baseline(a, w)
 
-    other = None
-    if not a.no_side and world > 1 and a.workload in ("dlrm_fused", "gather", "sasrec"):
-        first_placement = a.placement
-        alt = "rowshard" if first_placement == "replicated" else "replicated"
-        try:
-            del w
-            torch.cuda.empty_cache()
-            w2 = build(a.workload, alt)
-            wall2, dev2, launch2 = measure(w2)
-            other = {"placement": alt, "value": round(world * w2["units"] * a.steps / wall2, 1), "unit": "samples/s",
-                     "ms_per_step": round(wall2 / a.steps * 1e3, 4), "launch_us": launch2,
-                     "exchange": w2["sharded"].describe() if w2.get("sharded") is not None else None}
-        except Exception as e:  # noqa: BLE001  (a failing side measurement must not cost the headline line)
-            other = {"placement": alt, "error": f"{type(e).__name__}: {e}"[:300]}
-        a.placement = first_placement
-
+    res = None
     if rank == 0:
         res = {
             "metric": "forward samples/sec, Criteo-shape 65536x26 sparse x dim128",
@@ -424,12 +412,44 @@ def main():
                             "parallelism": f"dp{world}", "spinup_s": a.spinup}, **head["config"]),
             "roofline": roof,
         }
+        if w.get("sharded") is not None:
+            res["config"]["exchange"] = w["sharded"].describe()
         if gather_roof is not None:
             res["gather_roofline"] = gather_roof
-        if other is not None:
-            res[other["placement"]] = other
         if cpu_base is not None:
             res["cpu_baseline"] = cpu_base
+
+    # At N > 1 the OTHER placement is measured in the same run and reported beside the headline.  It runs under a
+    # watchdog: a collective that hangs must not cost the headline line (rank 0 prints what it has, every rank exits).
+    if not a.no_side and world > 1 and a.workload in ("dlrm_fused", "gather", "sasrec"):
+        import threading
+        first_placement = a.placement
+        alt = "rowshard" if first_placement == "replicated" else "replicated"
+
+        def give_up():
+            if rank == 0:
+                res[alt] = {"placement": alt, "error": f"timed out after {a.side_timeout:.0f} s"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        dog = threading.Timer(a.side_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            del w
+            torch.cuda.empty_cache()
+            w2 = build(a.workload, alt)
+            wall2, dev2, launch2 = measure(w2)
+            other = {"placement": alt, "value": round(world * w2["units"] * a.steps / wall2, 1), "unit": "samples/s",
+                     "ms_per_step": round(wall2 / a.steps * 1e3, 4), "launch_us": launch2,
+                     "exchange": w2["sharded"].describe() if w2.get("sharded") is not None else None}
+        except Exception as e:  # noqa: BLE001  (a failing side measurement must not cost the headline line)
+            other = {"placement": alt, "error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+        a.placement = first_placement
+        if rank == 0:
+            res[alt] = other
+
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

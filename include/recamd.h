@@ -290,13 +290,93 @@ int rec_adam_f32(float* var, float* m, float* v, const float* grad, int64_t n, f
  *   counts[g]      = number of ids owned by g             (device int32[G], zeroed by the call)
  *   perm[i]        = position of id i in the owner-sorted send buffer (stable within owner)
  *   send_local[p]  = id / G  at sorted position p
- * n ids (int32).  Deterministic (stable) so results are reproducible. */
+ * n ids (int32).  Deterministic (stable) so results are reproducible.  A negative id goes to owner 0 with local
+ * row -1 (zero row on the owner); INT32_MIN marks an id that is not to be sent at all (perm = -1). */
 int64_t rec_shard_bucket_workspace_bytes(int64_t n, int32_t G);
 int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, int32_t* counts,
                          int32_t* perm, int32_t* send_local, void* workspace, void* stream);
+/* The device part of a sharded lookup on its own (rec_shard_plan_ids = this + the count exchange): exact
+ * de-duplication of n virtual row ids + stable bucketing of the unique ones by owner.
+ *   rep_table  one int32 per virtual row, INT32_MAX between calls (NULL = no de-duplication)
+ *   first[i]   index of the first lookup that asks for the same row (-1 for a negative id)
+ *   uniq[i]    vids[i] if i is that first lookup, else INT32_MIN      perm[i]  its position in the send list, else -1
+ *   uidx[i]    position in the send list (= row of the returned buffer) that lookup i reads, -1 = zero row
+ *   send_local[p], counts[g]  as rec_shard_bucket_i32;  workspace: rec_shard_bucket_workspace_bytes(n, G) */
+int rec_shard_dedup_bucket_i32(const int32_t* vids, int64_t n, int32_t G, int32_t* rep_table, int32_t* first,
+                               int32_t* uniq, int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts,
+                               void* workspace, void* stream);
 /* out[i, :] = rows[perm[i], :]  (un-permute the returned rows), D floats per row */
 int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,
                            float* out, int64_t out_stride, void* stream);
+
+/* ---- C2 / C1: the exchange of the row-sharded lookup and the gradient merge, on RCCL over xGMI ----------
+ * The reference distributes with tf.distribute.MirroredStrategy only (replicated variables + NCCL gradient
+ * all-reduce inside fit(): src/ctr/fm/train.py:43-45 and nine more train scripts); these entry points are the
+ * north-star replacement: tables row-sharded cyclically over the `world` GPUs of one node (virtual row v =
+ * f * Vpad + id, owner = v % world, local row = v / world), one process per GPU.
+ *
+ * rec_comm: an opaque communicator.  rec_comm_init_rank creates an RCCL communicator (rank 0 obtains the 128-byte
+ * id with rec_comm_unique_id and hands it to the other ranks by any means); rec_comm_from_nccl borrows an existing
+ * ncclComm_t; rec_comm_create_with_transport takes caller-supplied collectives (another fabric, a test double);
+ * rec_comm_create_local builds `world` in-process communicators on one device whose collectives complete when the
+ * LAST simulated rank has entered them (tests: run each phase for every rank before the next phase). */
+typedef struct rec_comm rec_comm;
+typedef struct rec_transport {
+  void* ctx;
+  /* all-gather of `world` int32 send counts per rank into a (world x world) matrix, row p = rank p's counts */
+  int (*allgather_counts)(void* ctx, const int32_t* counts_dev, int32_t* matrix_dev, void* stream);
+  /* all-to-all(v) of elements of elem_bytes; counts and displacements in elements, HOST arrays of `world` entries */
+  int (*alltoallv)(void* ctx, int32_t rank, const void* send, const int64_t* send_counts, const int64_t* send_displ,
+                   void* recv, const int64_t* recv_counts, const int64_t* recv_displ, int32_t elem_bytes, void* stream);
+  /* in-place sum over ranks (may be NULL if rec_comm_allreduce_sum_f32 is never called) */
+  int (*allreduce_sum_f32)(void* ctx, int32_t rank, float* buf, int64_t n, void* stream);
+  int32_t deferred; /* 1: a collective's data movement is enqueued only when the last rank has entered it */
+} rec_transport;
+int rec_comm_unique_id(void* id128 /* host, 128 bytes out */);
+int rec_comm_init_rank(rec_comm** out, const void* id128, int32_t world, int32_t rank);
+int rec_comm_from_nccl(rec_comm** out, void* nccl_comm, int32_t world, int32_t rank);
+int rec_comm_create_with_transport(rec_comm** out, const rec_transport* t, int32_t world, int32_t rank);
+int rec_comm_create_local(int32_t world, rec_comm** comms_out /* host array of `world` handles */);
+int rec_comm_destroy(rec_comm* comm);
+int32_t rec_comm_world(const rec_comm* comm);
+int32_t rec_comm_rank(const rec_comm* comm);
+/* gradient merge of replicated (dense) parameters: buf <- sum over ranks, in place (MirroredStrategy's all-reduce) */
+int rec_comm_allreduce_sum_f32(rec_comm* comm, float* buf, int64_t n, void* stream);
+
+/* One sharded lookup of n virtual row ids (device int32; negative = out of range, answered with a zero row):
+ *   rec_shard_plan_ids     device: exact de-duplication (rep_table: one int32 per virtual row holding INT32_MAX
+ *                          between calls, or NULL = no de-duplication), stable bucketing of the unique ids by owner,
+ *                          all-gather of the send counts, asynchronous copy of the count matrix to pinned host
+ *                          memory behind an event.  A pipelined caller issues this for batch i+1 before it runs
+ *                          batch i, so rec_shard_plan_finish never waits.
+ *   rec_shard_plan_finish  host: waits for that event, derives the split sizes; returns the number of unique rows
+ *                          this rank will receive back (n_unique) and the number it must serve (n_recv).
+ *   rec_shard_exchange_ids all-to-all #1: local rows of the unique ids -> recv_local (n_recv int32)
+ *   rec_shard_serve_f32    served[i, :] = arena[recv_local[i], :]   (this rank's (arena_rows, D) shard)
+ *   rec_shard_exchange_rows_f32  reverse = 0: all-to-all #2, served (n_recv, D) -> dst (n_unique, D) in send order;
+ *                          reverse = 1: the backward direction, one gradient row per unique lookup (n_unique, D) ->
+ *                          dst (n_recv, D) aligned with recv_local for the owner's scatter-add.
+ *   rec_shard_lookup_f32   = finish + exchange_ids + serve + exchange_rows(forward).
+ * Lookup i then reads row rec_shard_plan_uidx()[i] of the returned rows (-1 = zero row): pass the buffer as the
+ * table and uidx as the ids of rec_gather_concat_f32 / rec_gather_pairwise_dot_f32 — no un-permute pass.
+ * workspace: rec_shard_plan_workspace_bytes(max_ids, world) bytes of device memory owned by the caller; it holds
+ * uidx and the send list and must stay untouched until the lookup's last use of them. */
+typedef struct rec_shard_plan rec_shard_plan;
+int64_t rec_shard_plan_workspace_bytes(int64_t max_ids, int32_t world);
+int rec_shard_plan_create(rec_comm* comm, int64_t max_ids, rec_shard_plan** out);
+int rec_shard_plan_destroy(rec_shard_plan* plan);
+int rec_shard_plan_ids(rec_shard_plan* plan, const int32_t* vids, int64_t n, int32_t* rep_table, void* workspace,
+                       void* stream);
+int rec_shard_plan_finish(rec_shard_plan* plan, int64_t* n_unique /* host out */, int64_t* n_recv /* host out */);
+const int32_t* rec_shard_plan_uidx(const rec_shard_plan* plan);
+int rec_shard_exchange_ids(rec_shard_plan* plan, int32_t* recv_local, void* stream);
+int rec_shard_serve_f32(rec_shard_plan* plan, const float* arena, int64_t arena_rows, int32_t D,
+                        const int32_t* recv_local, float* served, int32_t* oob_flag, void* stream);
+int rec_shard_exchange_rows_f32(rec_shard_plan* plan, const float* src, int32_t D, float* dst, int32_t reverse,
+                                void* stream);
+int rec_shard_lookup_f32(rec_shard_plan* plan, const float* arena, int64_t arena_rows, int32_t D, int32_t* recv_local,
+                         int64_t recv_cap, float* served, float* rows_out, int64_t rows_cap, int32_t* oob_flag,
+                         void* stream);
 
 /* ---- §8f-2 (first slice): the loss and the metric of every ctr train script --------------------------
  * model.compile(loss=binary_crossentropy, metrics=[AUC()]) / model.evaluate(...)[1]

@@ -327,6 +327,14 @@ PYBIND11_MODULE(_C, m) {
                                P<int32_t>(send_local), P<void>(ws), P<void>(stream)),
           "rec_shard_bucket_i32");
   });
+  m.def("shard_dedup_bucket_i32", [](ptr_t vids, int64_t n, int G, ptr_t rep, ptr_t first, ptr_t uniq, ptr_t perm,
+                                     ptr_t uidx, ptr_t send_local, ptr_t counts, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_dedup_bucket_i32(P<const int32_t>(vids), n, G, P<int32_t>(rep), P<int32_t>(first), P<int32_t>(uniq),
+                                     P<int32_t>(perm), P<int32_t>(uidx), P<int32_t>(send_local), P<int32_t>(counts),
+                                     P<void>(ws), P<void>(stream)),
+          "rec_shard_dedup_bucket_i32");
+  });
   m.def("unpermute_rows_f32", [](ptr_t rows, ptr_t perm, int64_t n, int D, ptr_t out,
                                  int64_t out_stride, ptr_t stream) {
     py::gil_scoped_release nogil;
@@ -334,4 +342,78 @@ PYBIND11_MODULE(_C, m) {
                                  P<float>(out), out_stride, P<void>(stream)),
           "rec_unpermute_rows_f32");
   });
+  // ---- communicator + sharded-lookup plan (opaque handles cross as integers) ----------------------------
+  m.def("comm_unique_id", []() {
+    char id[128];
+    check(rec_comm_unique_id(id), "rec_comm_unique_id");
+    return py::bytes(id, 128);
+  });
+  m.def("comm_init_rank", [](const std::string& id, int world, int rank) {
+    if (id.size() != 128) throw std::runtime_error("comm_init_rank: the unique id must be 128 bytes");
+    rec_comm* c = nullptr;
+    {
+      py::gil_scoped_release nogil;
+      check(rec_comm_init_rank(&c, id.data(), world, rank), "rec_comm_init_rank");
+    }
+    return reinterpret_cast<ptr_t>(c);
+  });
+  m.def("comm_create_local", [](int world) {
+    std::vector<rec_comm*> cs(world > 0 ? world : 0, nullptr);
+    check(rec_comm_create_local(world, cs.data()), "rec_comm_create_local");
+    std::vector<ptr_t> out;
+    for (rec_comm* c : cs) out.push_back(reinterpret_cast<ptr_t>(c));
+    return out;
+  });
+  m.def("comm_destroy", [](ptr_t c) { check(rec_comm_destroy(P<rec_comm>(c)), "rec_comm_destroy"); });
+  m.def("comm_world", [](ptr_t c) { return rec_comm_world(P<rec_comm>(c)); });
+  m.def("comm_rank", [](ptr_t c) { return rec_comm_rank(P<rec_comm>(c)); });
+  m.def("comm_allreduce_sum_f32", [](ptr_t c, ptr_t buf, int64_t n, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_comm_allreduce_sum_f32(P<rec_comm>(c), P<float>(buf), n, P<void>(stream)), "rec_comm_allreduce_sum_f32");
+  });
+  m.def("shard_plan_workspace_bytes", [](int64_t max_ids, int world) { return rec_shard_plan_workspace_bytes(max_ids, world); });
+  m.def("shard_plan_create", [](ptr_t comm, int64_t max_ids) {
+    rec_shard_plan* p = nullptr;
+    check(rec_shard_plan_create(P<rec_comm>(comm), max_ids, &p), "rec_shard_plan_create");
+    return reinterpret_cast<ptr_t>(p);
+  });
+  m.def("shard_plan_destroy", [](ptr_t p) { check(rec_shard_plan_destroy(P<rec_shard_plan>(p)), "rec_shard_plan_destroy"); });
+  m.def("shard_plan_ids", [](ptr_t p, ptr_t vids, int64_t n, ptr_t rep, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_plan_ids(P<rec_shard_plan>(p), P<const int32_t>(vids), n, P<int32_t>(rep), P<void>(ws), P<void>(stream)),
+          "rec_shard_plan_ids");
+  });
+  m.def("shard_plan_finish", [](ptr_t p) {
+    int64_t nu = 0, nr = 0;
+    {
+      py::gil_scoped_release nogil;
+      check(rec_shard_plan_finish(P<rec_shard_plan>(p), &nu, &nr), "rec_shard_plan_finish");
+    }
+    return std::make_tuple(nu, nr);
+  });
+  m.def("shard_plan_uidx", [](ptr_t p) { return reinterpret_cast<ptr_t>(rec_shard_plan_uidx(P<rec_shard_plan>(p))); });
+  m.def("shard_exchange_ids", [](ptr_t p, ptr_t recv_local, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_exchange_ids(P<rec_shard_plan>(p), P<int32_t>(recv_local), P<void>(stream)), "rec_shard_exchange_ids");
+  });
+  m.def("shard_serve_f32", [](ptr_t p, ptr_t arena, int64_t arena_rows, int D, ptr_t recv_local, ptr_t served, ptr_t oob,
+                              ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_serve_f32(P<rec_shard_plan>(p), P<const float>(arena), arena_rows, D, P<const int32_t>(recv_local),
+                              P<float>(served), P<int32_t>(oob), P<void>(stream)),
+          "rec_shard_serve_f32");
+  });
+  m.def("shard_exchange_rows_f32", [](ptr_t p, ptr_t src, int D, ptr_t dst, int reverse, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_exchange_rows_f32(P<rec_shard_plan>(p), P<const float>(src), D, P<float>(dst), reverse, P<void>(stream)),
+          "rec_shard_exchange_rows_f32");
+  });
+  m.def("shard_lookup_f32", [](ptr_t p, ptr_t arena, int64_t arena_rows, int D, ptr_t recv_local, int64_t recv_cap,
+                               ptr_t served, ptr_t rows_out, int64_t rows_cap, ptr_t oob, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_lookup_f32(P<rec_shard_plan>(p), P<const float>(arena), arena_rows, D, P<int32_t>(recv_local), recv_cap,
+                               P<float>(served), P<float>(rows_out), rows_cap, P<int32_t>(oob), P<void>(stream)),
+          "rec_shard_lookup_f32");
+  });
 }
+

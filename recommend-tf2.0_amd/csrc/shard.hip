@@ -16,8 +16,13 @@ namespace rec {
 constexpr int kChunk = 1024;  // ids per block: 4 rounds x 256 threads, index order = round, thread
 constexpr int kMaxG = 64;
 
+constexpr int32_t kSkip = INT32_MIN;  // "not in the send list": duplicates and (dedup path) out-of-range ids
+
 __device__ __forceinline__ void owner_of(int32_t id, int G, int& owner, int32_t& local) {
-  if (id < 0) {
+  if (id == kSkip) {
+    owner = -1;
+    local = -1;
+  } else if (id < 0) {
     owner = 0;
     local = -1;
   } else {
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void shard_hist_kernel(const int32_t* __restri
       int o;
       int32_t l;
       owner_of(ids[i], G, o, l);
-      atomicAdd(&h[o], 1);  // LDS integer atomics: order-independent, deterministic result
+      if (o >= 0) atomicAdd(&h[o], 1);  // LDS integer atomics: order-independent, deterministic result
     }
   }
   __syncthreads();
@@ -108,6 +113,8 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(const int32_t* __res
       for (int w2 = 0; w2 < wv; ++w2) pos += wcnt[w2][o];
       perm[i] = pos;
       send_local[pos] = l;
+    } else if (i < n) {
+      perm[i] = -1;  // skipped id: not in the send list
     }
     __syncthreads();
     if ((int)threadIdx.x < G)
@@ -115,6 +122,48 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(const int32_t* __res
                           wcnt[3][threadIdx.x];
     __syncthreads();
   }
+}
+
+// ---- exact per-lookup de-duplication (before the exchange) -----------------------------------------
+// rep[v] (one int32 per virtual row, INT32_MAX between calls) receives the smallest lookup index that asks for
+// row v: deterministic representative.  Representatives enter the send list, every lookup then reads the returned
+// row of its representative (uidx).  Out-of-range ids (negative after the caller's range check) are not sent at
+// all: uidx = -1, the consumer reads a zero row and raises the REQUESTER's oob flag.
+__global__ __launch_bounds__(256) void shard_first_kernel(const int32_t* __restrict__ vids, int64_t n,
+                                                          int32_t* __restrict__ rep) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = vids[i];
+  if (v >= 0) atomicMin(&rep[v], (int32_t)i);
+}
+
+__global__ __launch_bounds__(256) void shard_uniq_kernel(const int32_t* __restrict__ vids, int64_t n,
+                                                         const int32_t* __restrict__ rep, int32_t* __restrict__ first,
+                                                         int32_t* __restrict__ uniq) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = vids[i];
+  const int32_t f = v >= 0 ? (rep ? rep[v] : (int32_t)i) : -1;
+  first[i] = f;
+  uniq[i] = (f == (int32_t)i) ? v : kSkip;
+}
+
+__global__ __launch_bounds__(256) void shard_uidx_kernel(const int32_t* __restrict__ vids, int64_t n,
+                                                         const int32_t* __restrict__ first,
+                                                         const int32_t* __restrict__ perm, int32_t* __restrict__ rep,
+                                                         int32_t* __restrict__ uidx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t f = first[i];
+  uidx[i] = f >= 0 ? perm[f] : -1;
+  const int32_t v = vids[i];
+  if (rep && v >= 0) rep[v] = INT32_MAX;  // leave the table clean for the next call (duplicates write the same value)
+}
+
+// a += b (the in-process test transport's all-reduce)
+__global__ __launch_bounds__(256) void vec_add_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] += b[i];
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -176,6 +225,52 @@ extern "C" int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, in
                      perm, send_local);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
+}
+
+namespace rec {
+// device steps of rec_shard_plan_ids (shard_exchange.cpp): dedup (rep may be NULL) + stable bucketing of the
+// representatives.  ws_hist: rec_shard_bucket_workspace_bytes(n, G).
+int shard_plan_device(const int32_t* vids, int64_t n, int32_t G, int32_t* rep, int32_t* first, int32_t* uniq,
+                      int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts, void* ws_hist,
+                      hipStream_t st) {
+  const char* who = "rec_shard_plan_ids";
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * G, st);
+    REC_CHECK_ARG(e == hipSuccess, REC_EHIP, "%s: memset: %s", who, hipGetErrorString(e));
+    return REC_OK;
+  }
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (rep) {
+    hipLaunchKernelGGL(shard_first_kernel, dim3(nb), dim3(256), 0, st, vids, n, rep);
+    REC_CHECK_LAUNCH(who);
+  }
+  hipLaunchKernelGGL(shard_uniq_kernel, dim3(nb), dim3(256), 0, st, vids, n, (const int32_t*)rep, first, uniq);
+  REC_CHECK_LAUNCH(who);
+  int rc = rec_shard_bucket_i32(uniq, n, G, counts, perm, send_local, ws_hist, st);
+  if (rc != REC_OK) return rc;
+  hipLaunchKernelGGL(shard_uidx_kernel, dim3(nb), dim3(256), 0, st, vids, n, (const int32_t*)first,
+                     (const int32_t*)perm, rep, uidx);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+int shard_vec_add(float* a, const float* b, int64_t n, hipStream_t st) {
+  if (n <= 0) return REC_OK;
+  hipLaunchKernelGGL(vec_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n);
+  REC_CHECK_LAUNCH("rec_comm_allreduce_sum_f32");
+  return REC_OK;
+}
+}  // namespace rec
+
+extern "C" int rec_shard_dedup_bucket_i32(const int32_t* vids, int64_t n, int32_t G, int32_t* rep_table, int32_t* first,
+                                          int32_t* uniq, int32_t* perm, int32_t* uidx, int32_t* send_local,
+                                          int32_t* counts, void* workspace, void* stream) {
+  const char* who = "rec_shard_dedup_bucket_i32";
+  REC_CHECK_ARG(G >= 1 && G <= kMaxG && n >= 0 && n <= 0x7fffffffLL, REC_ESHAPE, "%s: n=%lld G=%d", who, (long long)n, G);
+  REC_CHECK_ARG(counts && workspace && (n == 0 || (vids && first && uniq && perm && uidx && send_local)), REC_EINVAL,
+                "%s: NULL pointer", who);
+  return rec::shard_plan_device(vids, n, G, rep_table, first, uniq, perm, uidx, send_local, counts, workspace,
+                                reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,

@@ -1,9 +1,10 @@
-"""N > 1 path of the row-sharded lookup, world_size 2 and 3 over gloo on the CPU.
+"""N > 1 path of the row-sharded lookup and of the gradient merge, world_size 2 and 3 over gloo on the CPU.
 
-The transport logic (owner bucketing contract, split sizes, the two all-to-alls, un-permute) is the
-product code (recamd.dist.ShardedTables); the three DEVICE steps are replaced by a numpy-oracle
-stand-in injected by the test (tests may use the oracle; the product has no CPU path).  The result
-must be bit-identical to the single-device gather+concat of the oracle."""
+The transport logic (virtual ids, de-duplication contract, split sizes from the gathered count matrix, the two
+all-to-alls, reading the returned rows through uidx, the reverse all-to-all of the backward, the all-reduce) is the
+product code (recamd.dist.ShardedTables, transport 'torch'); the DEVICE steps are replaced by the numpy stand-ins of
+tests/shard_oracle.py (tests may use the oracle; the product has no CPU path).  Results must be bit-identical to the
+single-device gather+concat of the oracle."""
 import os
 import socket
 
@@ -14,28 +15,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-class OracleKernels:
-    """CPU stand-ins with the exact contract of the HIP kernels (stable bucketing, zero row on OOB)."""
-
-    def bucket(self, vids, G):
-        v = vids.numpy()
-        owner = np.where(v < 0, 0, v % G)
-        local = np.where(v < 0, -1, v // G).astype(np.int32)
-        order = np.argsort(owner, kind="stable")
-        perm = np.empty(len(v), np.int32)
-        perm[order] = np.arange(len(v), dtype=np.int32)
-        counts = np.bincount(owner, minlength=G).astype(np.int32)
-        return torch.from_numpy(counts), torch.from_numpy(perm), torch.from_numpy(local[order])
-
-    def gather(self, arena2d, local_rows, oob_flag=None):
-        from oracle import ref_numpy as ref
-        return torch.from_numpy(ref.embedding_lookup(arena2d.numpy(), local_rows.numpy(), oob="zero"))
-
-    def unpermute(self, rows, perm, out):
-        out.copy_(rows[perm.long()])
-        return out
-
-
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -44,36 +23,81 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, vocabs, D, B, seed, ret):
+def _batch(seed, rank, vocabs, B):
+    rng_i = np.random.default_rng(seed + 1 + rank)
+    ids = np.stack([rng_i.integers(-1, v + 1, size=B) for v in vocabs], axis=1).astype(np.int32)  # incl. OOB
+    ids[B // 2:] = ids[: B - B // 2]                                                              # ... and duplicates
+    return ids
+
+
+def _worker(rank, world, port, vocabs, D, B, seed, dedup, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from oracle import ref_numpy as ref
         from recamd.dist import ShardedTables, shard_table
+        from tests.shard_oracle import OracleKernels
         rng = np.random.default_rng(seed)  # every rank builds the same global tables
         tables = [rng.normal(size=(v, D)).astype(np.float32) for v in vocabs]
-        rng_i = np.random.default_rng(seed + 1 + rank)  # ... and its own batch
-        ids = np.stack([rng_i.integers(-1, v + 1, size=B) for v in vocabs], axis=1).astype(np.int32)  # incl. OOB
+        ids = _batch(seed, rank, vocabs, B)
         st = ShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in tables], vocabs, rank, world,
-                           kernels=OracleKernels())
-        out = st.lookup(torch.from_numpy(ids)).numpy()
-        from oracle import ref_numpy as ref
+                           kernels=OracleKernels(dedup), dedup=dedup)
+        flag = torch.zeros(1, dtype=torch.int32)
+        t_ids = torch.from_numpy(ids)
+        st.prefetch(t_ids)                                    # the pipelined form: plan first, look up later
+        out, plan = st.lookup(t_ids, oob_flag=flag, keep_plan=True)
         exp = ref.gather_concat(tables, ids, oob="zero")
-        ret[rank] = bool(np.array_equal(out.view(np.uint32), exp.view(np.uint32)))
+        ok = bool(np.array_equal(out.numpy().view(np.uint32), exp.view(np.uint32)))
+        has_oob = bool(((ids < 0) | (ids >= np.asarray(vocabs)[None, :])).any())
+        ok = ok and int(flag.item()) == int(has_oob) and st.stats["prefetch_hits"] == 1
+        if dedup:
+            ok = ok and st.stats["unique_sent"] < st.stats["ids"]
+
+        # backward: every rank's dy, summed at the owners == the oracle's dense gradient over ALL ranks' lookups
+        dys = [np.random.default_rng(seed + 100 + r).normal(size=(B, len(vocabs) * D)).astype(np.float32) for r in range(world)]
+        grad_arena = torch.zeros_like(st.arena)
+        st.backward(plan, torch.from_numpy(dys[rank]), grad_arena)
+        full = [np.zeros((v, D), np.float64) for v in vocabs]
+        for r in range(world):
+            g = ref.embedding_grad(_batch(seed, r, vocabs, B), dys[r], vocabs, [D] * len(vocabs))
+            for f in range(len(vocabs)):
+                full[f] += g[f]
+        for f, v in enumerate(vocabs):
+            mine = grad_arena[f * st.rows_local: f * st.rows_local + len(range(rank, v, world))].numpy()
+            ok = ok and bool(np.allclose(mine, full[f][rank::world], rtol=1e-5, atol=1e-6))
+
+        # dense-parameter gradient merge
+        t = torch.full((5,), float(rank + 1))
+        st.allreduce_sum_(t)
+        ok = ok and bool(torch.equal(t, torch.full((5,), float(world * (world + 1) // 2))))
+
+        # the DLRM sparse stage through the exchange (second lookup of the same ids: plans on the spot)
+        dense = torch.from_numpy(np.random.default_rng(seed + 7 + rank).normal(size=(B, D)).astype(np.float32))
+        z = st.lookup_pairwise_dot(t_ids, dense).numpy()
+        X = np.concatenate([exp.reshape(B, len(vocabs), D), dense.numpy()[:, None, :]], axis=1)
+        ok = ok and bool(np.array_equal(z[:, :-D], ref.pairwise_dot(X).astype(np.float32))) and \
+            bool(np.array_equal(z[:, -D:], dense.numpy()))
+        ret[rank] = ok
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,vocabs,D,B", [(2, [10, 33, 7, 100], 8, 57), (3, [50, 5, 64], 4, 20), (2, [1000] * 26, 16, 128)])
-def test_sharded_lookup_gloo(world, vocabs, D, B):
-    import tests.conftest  # noqa: F401  (sys.path for spawned children comes from PYTHONPATH below)
+def _spawn(fn, world, *args):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.environ["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "recommend-tf2.0_amd"),
                                                 os.environ.get("PYTHONPATH", "")])
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), vocabs, D, B, 123, ret), nprocs=world, join=True)
-    assert all(ret.get(r) for r in range(world)), dict(ret)
+    mp.spawn(fn, args=(world, _free_port()) + args + (ret,), nprocs=world, join=True)
+    return dict(ret)
+
+
+@pytest.mark.parametrize("world,vocabs,D,B,dedup", [(2, [10, 33, 7, 100], 8, 57, True), (3, [50, 5, 64], 4, 20, True),
+                                                    (2, [1000] * 26, 16, 128, True), (2, [10, 33, 7, 100], 8, 57, False)])
+def test_sharded_lookup_backward_allreduce_gloo(world, vocabs, D, B, dedup):
+    ret = _spawn(_worker, world, vocabs, D, B, 123, dedup)
+    assert all(ret.get(r) for r in range(world)), ret
 
 
 def test_shard_helpers():
@@ -87,3 +111,23 @@ def test_shard_helpers():
             assert torch.equal(s, t[r::world])
             tot += s.shape[0]
         assert tot == 10
+
+
+def test_dedup_bucket_contract():
+    """the numpy specification itself: representatives are first occurrences, send order is stable by owner"""
+    from tests.shard_oracle import dedup_bucket_np
+    v = np.array([5, -1, 9, 5, 4, 9, 9, 2], np.int32)
+    counts, uidx, send_local, first, perm = dedup_bucket_np(v, 2)
+    # unique reps: i=0 (5, owner 1), 2 (9, owner 1), 4 (4, owner 0), 7 (2, owner 0) -> send order: 4, 2 | 5, 9
+    assert counts.tolist() == [2, 2]
+    assert send_local.tolist() == [2, 1, 2, 4]
+    assert first.tolist() == [0, -1, 2, 0, 4, 2, 2, 7]
+    assert uidx.tolist() == [2, -1, 3, 2, 0, 3, 3, 1]
+
+
+def test_int64_ids_are_range_checked_before_narrowing():
+    from recamd.dist import ShardedTables
+    from tests.shard_oracle import OracleKernels
+    st = ShardedTables([torch.zeros((10, 4))], [10], 0, 1, kernels=OracleKernels())
+    v = st._vids(torch.tensor([[3], [2 ** 32 + 3], [-7], [9]], dtype=torch.int64))
+    assert v.tolist() == [3, -1, -1, 9]

@@ -278,6 +278,54 @@ def test_sasrec(dev, blocks, heads, last_row_only):
     assert np.all(logits[0] == 0.0)
 
 
+@pytest.mark.parametrize("G", [1, 8])
+def test_sasrec_row_sharded_simulated_ranks(dev, G):
+    """BASELINE configs[4] as stated: SASRec S=200, d=64 with the seq/pos/neg tables row-sharded (row % G) behind the
+    sharded lookup, G ranks simulated on one GPU (transport 'peers': each rank's requests are served from the owner's
+    shard, which is what the RCCL all-to-all pair delivers; the exchange itself is covered by tests/test_shard_gpu.py
+    and tests/test_dist_cpu.py).  Every rank's logits equal the oracle's sasrec_forward on the UNSHARDED tables."""
+    from match.sasrec.model import SASRec
+    from recamd.dist import shard_table
+    rng = np.random.default_rng(50 + G)
+    V, S, n, B, d = 5000, 200, 100, 24, 64
+    uf = [{'feat': 'seq_item', 'feat_num': V, 'feat_len': S, 'embed_dim': d},
+          {'feat': 'pos_item', 'feat_num': V, 'feat_len': 1, 'embed_dim': d},
+          {'feat': 'neg_item', 'feat_num': V, 'feat_len': n, 'embed_dim': d}]
+    full = SASRec(uf, [], blocks=1, num_heads=1, att_hidden_unit=d, seq_len=S, neg_len=n)
+
+    def batch():
+        lens = rng.integers(0, S + 1, size=B)
+        seq = rng.integers(1, V, size=(B, S))
+        seq[np.arange(S)[None, :] < (S - lens)[:, None]] = 0
+        return [seq.astype(np.int32), rng.integers(0, V, size=(B, 1)).astype(np.int32),
+                rng.integers(0, V, size=(B, n)).astype(np.int32)]
+    full(batch())
+    randomize(full, rng, 0.15)
+    w = full.get_weights()
+    tabs = {k: w[f'user_embed_{k}/embeddings'] for k in ('seq_item', 'pos_item', 'neg_item')}
+    ranks = [SASRec(uf, [], blocks=1, num_heads=1, att_hidden_unit=d, seq_len=S, neg_len=n, sharded=(r, G),
+                    shard_transport="peers" if G > 1 else None) for r in range(G)]
+    if G > 1:
+        for m in ranks:
+            m._sharded.link_peers([x._sharded for x in ranks])
+    for r, m in enumerate(ranks):
+        m(batch())                                                    # builds the lazily created layers
+        ws = {k: v for k, v in w.items() if not k.startswith('user_embed_')}
+        for k, t in tabs.items():
+            ws[f'user_embed_{k}/embeddings'] = shard_table(torch.from_numpy(t), r, G).numpy()
+        m.set_weights(ws)
+    for r in range(G):
+        seq, pos, neg = batch()
+        logits = ranks[r]([seq, pos, neg]).cpu().numpy()
+        exp, loss = ref.sasrec_forward(seq, pos, neg, tabs['seq_item'], tabs['pos_item'], tabs['neg_item'],
+                                       [_sasrec_params(w, 0)], 1)
+        assert close(logits, exp, 2e-5)
+        assert abs(float(ranks[r].losses[0]) - loss) <= 1e-5 * max(1.0, abs(loss))
+        if G > 1:
+            st = ranks[r]._sharded.describe()
+            assert st["unique_sent"] < st["ids"]                      # pad ids dropped + duplicates merged
+
+
 def test_youtube_dnn_towers(dev):
     from match.youtube_dnn.model import YoutubeDNN
     rng = np.random.default_rng(6)

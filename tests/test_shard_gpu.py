@@ -49,34 +49,151 @@ def test_sharded_tables_world1_hip(dev):
     assert np.array_equal(out.view(np.uint32), ref.gather_concat(tables, ids, oob="zero").view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [0, 1, 7, 1024, 1025, 50_003])
+@pytest.mark.parametrize("G", [1, 2, 8, 7])
+@pytest.mark.parametrize("dedup", [True, False])
+def test_dedup_bucket_matches_numpy_contract(dev, n, G, dedup):
+    """rec_shard_dedup_bucket_i32 == tests/shard_oracle.dedup_bucket_np, integer for integer, and the
+    representative table is left clean (all INT32_MAX) for the next call."""
+    from recamd.dist import HipKernels
+    from tests.shard_oracle import dedup_bucket_np
+    rng = np.random.default_rng(n * 3 + G)
+    R = 5000
+    vids = rng.integers(0, R, size=n).astype(np.int32)          # many duplicates
+    if n > 3:
+        vids[1] = -1
+        vids[n - 1] = vids[0]
+    rep = torch.full((R,), 2 ** 31 - 1, dtype=torch.int32, device=dev) if dedup else None
+    counts, uidx, send_local = HipKernels().dedup_bucket(torch.from_numpy(vids).to(dev), G, rep)
+    e_counts, e_uidx, e_send, _, _ = dedup_bucket_np(vids, G, dedup)
+    assert np.array_equal(counts.cpu().numpy(), e_counts)
+    assert np.array_equal(uidx.cpu().numpy(), e_uidx)
+    assert np.array_equal(send_local.cpu().numpy()[:len(e_send)], e_send)
+    if dedup:
+        assert int((rep != 2 ** 31 - 1).sum().item()) == 0
+
+
 @pytest.mark.parametrize("G", [2, 8])
-def test_sharded_lookup_simulated_ranks_hip(dev, G):
-    """All G ranks simulated on ONE GPU with the real HIP kernels (bucket -> route -> owner gather
-    -> route back -> un-permute): every rank's result equals the unsharded oracle bit-for-bit."""
+@pytest.mark.parametrize("dedup", [True, False])
+def test_cabi_exchange_simulated_ranks(dev, G, dedup):
+    """The C-ABI exchange (rec_shard_plan_* / rec_shard_exchange_* / rec_shard_serve_f32) with G simulated ranks on ONE
+    GPU over the in-process transport (rec_comm_create_local): every phase is run for every rank before the next one.
+    Forward: each rank's lookup == the unsharded oracle bit for bit, read through uidx by the real consumer kernels
+    (gather+concat and the fused pairwise dot).  Backward: the reverse all-to-all + owner scatter-add == the oracle's
+    dense gradient over all ranks' lookups.  All-reduce: sum over ranks."""
     from oracle import ref_numpy as ref
     from recamd import ops
+    from recamd._lib import C
     from recamd.dist import ShardedTables, shard_table
     rng = np.random.default_rng(G)
-    vocabs, D, B = [1000] * 6, 32, 200
+    F, D, B, V = 6, 128, 150, 400
+    vocabs = [V - f for f in range(F)]
     tables = [rng.normal(size=(v, D)).astype(np.float32) for v in vocabs]
-    ranks = [ShardedTables([shard_table(torch.from_numpy(t), r, G).to(dev) for t in tables], vocabs, r, G) for r in range(G)]
-    ids = [np.stack([rng.integers(0, v, size=B) for v in vocabs], axis=1).astype(np.int32) for _ in range(G)]
-    # step 1: bucket on every rank
-    buck = []
+    comms = C.comm_create_local(G)
+    st = [ShardedTables([shard_table(torch.from_numpy(t), r, G).to(dev) for t in tables], vocabs, r, G,
+                        transport="torch", dedup=dedup) for r in range(G)]   # used for arena / vids / rep only
+    ids = [np.stack([rng.integers(-1, v + 1, size=B) for v in vocabs], axis=1).astype(np.int32) for _ in range(G)]
     for r in range(G):
-        st = ranks[r]
-        t = torch.from_numpy(ids[r]).to(dev)
-        vids = (t + st._shift).reshape(-1).contiguous()
-        counts, perm, send_local = ops.shard_bucket(vids, G)
-        buck.append((counts.cpu().numpy(), perm, send_local))
-    # step 2-4: route requests to owners, gather there, route rows back
+        ids[r][B // 2:] = ids[r][:B - B // 2]
+        if r % 2 == 0:
+            ids[r][0, 0] = -3                                              # make sure some ranks do have a bad id
+    stream = torch.cuda.current_stream().cuda_stream
+    n = B * F
+    plans, wss, vids = [], [], []
+    for r in range(G):                                                     # phase 1: plan
+        plans.append(C.shard_plan_create(comms[r], n))
+        wss.append(torch.empty(C.shard_plan_workspace_bytes(n, G), dtype=torch.uint8, device=dev))
+        vids.append(st[r]._vids(torch.from_numpy(ids[r]).to(dev)))
+        C.shard_plan_ids(plans[r], vids[r].data_ptr(), n, st[r]._rep.data_ptr() if dedup else 0, wss[r].data_ptr(), stream)
+    sizes = [C.shard_plan_finish(plans[r]) for r in range(G)]              # phase 2: host split sizes
+    if dedup:
+        assert all(nu < n for nu, _ in sizes)
+    recv_local = [torch.empty(max(1, nr), dtype=torch.int32, device=dev) for _, nr in sizes]
+    served = [torch.empty((max(1, nr), D), dtype=torch.float32, device=dev) for _, nr in sizes]
+    rows = [torch.empty((max(1, nu), D), dtype=torch.float32, device=dev) for nu, _ in sizes]
+    for r in range(G):                                                     # phase 3: all-to-all #1
+        C.shard_exchange_ids(plans[r], recv_local[r].data_ptr(), stream)
+    for r in range(G):                                                     # phase 4: owner-side gather
+        C.shard_serve_f32(plans[r], st[r].arena.data_ptr(), st[r].arena.shape[0], D, recv_local[r].data_ptr(),
+                          served[r].data_ptr(), 0, stream)
+    for r in range(G):                                                     # phase 5: all-to-all #2
+        C.shard_exchange_rows_f32(plans[r], served[r].data_ptr(), D, rows[r].data_ptr(), 0, stream)
+    dys = [rng.normal(size=(B, F * D)).astype(np.float32) for _ in range(G)]
+    d_rows, d_served, uidxs = [], [], []
+    for r in range(G):                                                     # consumers + backward scatter by uidx
+        off = C.shard_plan_uidx(plans[r]) - wss[r].data_ptr()
+        uidx = wss[r][off: off + 4 * n].view(torch.int32)
+        uidxs.append(uidx)
+        nu = sizes[r][0]
+        flag = ops.new_oob_flag(dev)
+        g = ops.TableGroup([rows[r][:nu]] * F, out_cols=[f * D for f in range(F)])
+        out = ops.gather_concat(g, uidx.view(B, F), oob_flag=flag).cpu().numpy()
+        exp = ref.gather_concat(tables, ids[r], oob="zero")
+        assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+        has_oob = bool(((ids[r] < 0) | (ids[r] >= np.asarray(vocabs)[None, :])).any())
+        assert int(flag.item()) == int(has_oob)                            # raised on the REQUESTING rank
+        dr = torch.zeros((max(1, nu), D), dtype=torch.float32, device=dev)
+        ops.embedding_grad(ops.TableGroup([dr[:nu]]), uidx.view(-1, 1), torch.from_numpy(dys[r]).to(dev).view(-1, D))
+        d_rows.append(dr)
+        d_served.append(torch.empty((max(1, sizes[r][1]), D), dtype=torch.float32, device=dev))
+    for r in range(G):                                                     # phase 6: reverse all-to-all
+        C.shard_exchange_rows_f32(plans[r], d_rows[r].data_ptr(), D, d_served[r].data_ptr(), 1, stream)
+    full = [np.zeros((v, D), np.float64) for v in vocabs]
     for r in range(G):
-        counts, perm, send_local = buck[r]
-        offs = np.concatenate([[0], np.cumsum(counts)])
-        rows = torch.empty((B * len(vocabs), D), dtype=torch.float32, device=dev)
-        for o in range(G):
-            req = send_local[offs[o]:offs[o + 1]].contiguous()
-            served = ranks[o].kernels.gather(ranks[o].arena, req)
-            rows[offs[o]:offs[o + 1]] = served
-        out = ops.unpermute_rows(rows, perm).view(B, -1).cpu().numpy()
-        assert np.array_equal(out.view(np.uint32), ref.gather_concat(tables, ids[r]).view(np.uint32))
+        gr = ref.embedding_grad(ids[r], dys[r], vocabs, [D] * F)
+        for f in range(F):
+            full[f] += gr[f]
+    for r in range(G):                                                     # owner-side scatter-add
+        ga = torch.zeros_like(st[r].arena)
+        nr = sizes[r][1]
+        if nr:
+            ops.embedding_grad(ops.TableGroup([ga]), recv_local[r][:nr].view(-1, 1), d_served[r][:nr])
+        ga = ga.cpu().numpy()
+        for f, v in enumerate(vocabs):
+            mine = ga[f * st[r].rows_local: f * st[r].rows_local + len(range(r, v, G))]
+            assert np.allclose(mine, full[f][r::G], rtol=1e-5, atol=1e-5)
+    bufs = [torch.full((1000,), float(r + 1), device=dev) for r in range(G)]
+    for r in range(G):                                                     # gradient merge of dense parameters
+        C.comm_allreduce_sum_f32(comms[r], bufs[r].data_ptr(), 1000, stream)
+    torch.cuda.synchronize()
+    for r in range(G):
+        assert torch.equal(bufs[r], torch.full((1000,), float(G * (G + 1) // 2), device=dev))
+        C.shard_plan_destroy(plans[r])
+        C.comm_destroy(comms[r])
+
+
+def test_rccl_world1_executes(dev):
+    """A real RCCL communicator (one rank: the only size a one-GPU box offers): unique id, ncclCommInitRank, the
+    all-gather of the counts, grouped send/recv to self for both all-to-alls, the all-reduce — through the C ABI."""
+    from oracle import ref_numpy as ref
+    from recamd import ops
+    from recamd._lib import C
+    from recamd.dist import Comm
+    comm = Comm(0, 1)
+    assert C.comm_world(comm.handle) == 1 and C.comm_rank(comm.handle) == 0
+    rng = np.random.default_rng(3)
+    V, D, n = 300, 64, 1000
+    table = rng.normal(size=(V, D)).astype(np.float32)
+    vids = rng.integers(-1, V, size=n).astype(np.int32)
+    t_tab, t_v = torch.from_numpy(table).to(dev), torch.from_numpy(vids).to(dev)
+    rep = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+    plan = C.shard_plan_create(comm.handle, n)
+    ws = torch.empty(C.shard_plan_workspace_bytes(n, 1), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    C.shard_plan_ids(plan, t_v.data_ptr(), n, rep.data_ptr(), ws.data_ptr(), stream)
+    nu, nr = C.shard_plan_finish(plan)
+    assert nu == nr == len(np.unique(vids[vids >= 0]))
+    recv_local = torch.empty(nr, dtype=torch.int32, device=dev)
+    served = torch.empty((nr, D), dtype=torch.float32, device=dev)
+    rows = torch.empty((nu, D), dtype=torch.float32, device=dev)
+    C.shard_lookup_f32(plan, t_tab.data_ptr(), V, D, recv_local.data_ptr(), nr, served.data_ptr(), rows.data_ptr(), nu, 0,
+                       stream)
+    off = C.shard_plan_uidx(plan) - ws.data_ptr()
+    uidx = ws[off: off + 4 * n].view(torch.int32)
+    out = ops.gather_concat(ops.TableGroup([rows]), uidx.view(-1, 1)).cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), ref.embedding_lookup(table, vids, oob="zero").view(np.uint32))
+    t = torch.arange(16, dtype=torch.float32, device=dev)
+    comm.allreduce_sum_(t)
+    assert torch.equal(t.cpu(), torch.arange(16, dtype=torch.float32))
+    C.shard_plan_destroy(plan)
+    comm.destroy()
