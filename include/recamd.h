@@ -285,6 +285,58 @@ int rec_embedding_grad_f32(const rec_table_desc* grads, int32_t F, const void* i
 int rec_adam_f32(float* var, float* m, float* v, const float* grad, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t step, float l2, void* stream);
 
+/* ---- T2: backward of the path's layers (what Keras' fit() differentiates: src/ctr/deep_fm/train.py:58-65) --------
+ * GEMM-shaped parts of a Dense backward reuse rec_dense_f32:  dX = dY W^T = dense(dY, transpose(W)),
+ * dW = X^T dY = dense(transpose(X), dY);  the rest are row / column passes. */
+int rec_transpose_f32(const float* x, int64_t M, int64_t N, int64_t x_stride, float* out /* (N, M) */, void* stream);
+/* dy <- dy * act'(.) evaluated from the layer OUTPUT y (relu / sigmoid / tanh; REC_ACT_NONE is a no-op) */
+int rec_act_grad_f32(float* dy, int64_t dy_stride, const float* y, int64_t y_stride, int64_t M, int64_t N, int32_t act,
+                     void* stream);
+/* out[n] = sum_m row_w[m] * a[m,n] * b[m,n]   (b and row_w may be NULL); deterministic: fixed summation order,
+ * fp64 across 256-row chunks.  Bias gradients, BN statistics, dw of the cross layers. */
+int64_t rec_colsum_workspace_bytes(int64_t M, int64_t N);
+int rec_colsum_f32(const float* a, int64_t a_stride, const float* b, int64_t b_stride, const float* row_w, int64_t M,
+                   int64_t N, float* out, void* workspace, void* stream);
+/* tf.keras.layers.BatchNormalization(training=True) on (M, N) (src/ctr/layers/modules.py:131, din/model.py:83):
+ * batch mean / biased variance, y = gamma (x - mean) rsqrt(var + eps) + beta, moving <- moving * momentum +
+ * batch * (1 - momentum).  save_mean / save_inv (N floats each) feed the backward.  gamma/beta/moving_* may be NULL.
+ * workspace: rec_colsum_workspace_bytes(M, N). */
+int rec_bn_train_f32(const float* x, int64_t x_stride, int64_t M, int64_t N, const float* gamma, const float* beta,
+                     float eps, float momentum, float* moving_mean, float* moving_var, float* y, int64_t y_stride,
+                     float* save_mean, float* save_inv, void* workspace, void* stream);
+int64_t rec_bn_train_grad_workspace_bytes(int64_t M, int64_t N);
+int rec_bn_train_grad_f32(const float* x, int64_t x_stride, const float* dy, int64_t dy_stride, int64_t M, int64_t N,
+                          const float* gamma, const float* save_mean, const float* save_inv, float* dx,
+                          int64_t dx_stride, float* dgamma, float* dbeta, void* workspace, void* stream);
+/* dlogit[i] = scale * d BCE_keras(y_i, sigmoid(z_i)) / dz_i given p = sigmoid(z) (the loss of rec_binary_crossentropy_f32;
+ * scale = 1/n for the mean) */
+int rec_bce_sigmoid_grad_f32(const float* y_true, const float* p, int64_t n, float scale, float* dlogit, void* stream);
+/* Backward of rec_gather_pairwise_dot_f32 (int32 ids): dz (B, P [+ D]) -> embedding-row gradients atomically added into
+ * grad_tables (same shapes as tables; duplicates sum, out-of-range ids contribute nothing) and d_dense (B, D). */
+int rec_gather_pairwise_dot_grad_f32(const rec_table_desc* tables, const rec_table_desc* grad_tables, int32_t F,
+                                     const int32_t* ids, int64_t ids_stride, const float* dense, int64_t dense_stride,
+                                     int64_t B, const float* dz, int64_t dz_stride, int32_t append_dense, float* d_dense,
+                                     int64_t d_dense_stride, void* stream);
+/* Backward of rec_fm_layer_f32 (src/ctr/layers/modules.py:57-72): dout (B) -> d_first (B, L1; may be NULL),
+ * d_second (B, M), dw (L1).  The first-order term is ONE scalar for the whole batch, so d_first rows are all equal. */
+int64_t rec_fm_layer_grad_workspace_bytes(int64_t B, int64_t L1);
+int rec_fm_layer_grad_f32(const float* first, int64_t first_stride, int64_t L1, const float* second,
+                          int64_t second_stride, int64_t M, const float* w, const float* dout, int64_t B, float* d_first,
+                          int64_t d_first_stride, float* d_second, int64_t d_second_stride, float* dw, void* workspace,
+                          void* stream);
+/* One cross layer backward (src/ctr/layers/modules.py:105-112; contiguous (B, dim) operands): given g = dL/dx_{l+1},
+ * in place g <- dL/dx_l, dx0 += g s_l, ds[b] = g_b . x0_b  (then dw_l = rec_colsum_f32(xl, row_w = ds), db_l =
+ * rec_colsum_f32 of the incoming g). */
+int rec_cross_layer_grad_f32(const float* x0, const float* xl, const float* w, int64_t dim, int64_t B, float* g,
+                             float* dx0, float* ds, void* stream);
+/* "Lazy" row-wise Adam over the rows the batch touched (each exactly once: `stamp` holds one int32 per row, the last
+ * step that updated it).  DEVIATION from the reference, which applies Adam + the dense l2 gradient to EVERY row each
+ * step (rec_adam_f32 is that exact form): untouched rows keep var, m and v.  The touched rows' gradients are cleared. */
+int rec_adam_rows_f32(const rec_table_desc* var, const rec_table_desc* m, const rec_table_desc* v,
+                      const rec_table_desc* grad, const rec_table_desc* stamp, int32_t F, const int32_t* ids,
+                      int64_t ids_stride, int64_t B, float lr, float beta1, float beta2, float eps, int64_t step, float l2,
+                      void* stream);
+
 /* ---- C2: row-sharded lookup helpers (exchange itself = RCCL all-to-all issued by the host) --
  * Bucket a flat id list by owner rank for cyclic row sharding (owner = id % G, local = id / G):
  *   counts[g]      = number of ids owned by g             (device int32[G], zeroed by the call)

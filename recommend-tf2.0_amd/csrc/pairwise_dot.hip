@@ -288,6 +288,50 @@ __global__ __launch_bounds__(256) void pairdot_generic_kernel(const float* __res
   }
 }
 
+// Generic fused fallback (any n <= 64 rows, any D): one wave per sample, the gathered rows staged in LDS.
+__global__ __launch_bounds__(256) void pairdot_generic_gather_kernel(TableSet ts, int F, const void* __restrict__ ids,
+                                                                     int ids_f32, int64_t ids_stride,
+                                                                     const float* __restrict__ dense,
+                                                                     int64_t dense_stride, int64_t B, int D,
+                                                                     float* __restrict__ out, int64_t out_stride,
+                                                                     int append_dense, int* __restrict__ oob) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  const int n = F + (dense ? 1 : 0);
+  float* tile = lds + (size_t)w * n * (D + 1);
+  if (b < B) {
+    for (int i = 0; i < n; ++i) {
+      const float* src = nullptr;
+      if (i < F) {
+        const int32_t id = ids_f32 ? load_id<1>(ids, b * ids_stride + i) : load_id<0>(ids, b * ids_stride + i);
+        if ((uint32_t)id < (uint32_t)ts.vocab[i]) src = ts.base[i] + (int64_t)id * D;
+        else if (oob && lane == 0) *oob = 1;
+      } else {
+        src = dense + b * dense_stride;
+      }
+      for (int c = lane; c < D; c += 64) tile[i * (D + 1) + c] = src ? src[c] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (b >= B) return;
+  const int P = n * (n - 1) / 2;
+  for (int p = lane; p < P; p += 64) {
+    int i = (int)((1.f + sqrtf(1.f + 8.f * (float)p)) * 0.5f);
+    while (i * (i - 1) / 2 > p) --i;
+    while ((i + 1) * i / 2 <= p) ++i;
+    const int j = p - i * (i - 1) / 2;
+    const float* xi = tile + i * (D + 1);
+    const float* xj = tile + j * (D + 1);
+    float acc = 0.f;
+    for (int k = 0; k < D; ++k) acc = fmaf(xi[k], xj[k], acc);
+    out[b * out_stride + p] = acc;
+  }
+  if (append_dense)
+    for (int c = lane; c < D; c += 64) out[b * out_stride + P + c] = tile[(n - 1) * (D + 1) + c];
+}
+
 int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const char* who);
 // D = 128 fused form on the LDS-DMA ring + fp32 matrix cores (pairwise_dot_ring.hip): the default for the shapes it
 // covers (int32 ids, 16-B aligned padded output rows).  REC_PAIRDOT_IMPL=valu (read once) keeps the register-tiled
@@ -420,7 +464,18 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   }
   REC_PAIRDOT_SHAPES(REC_TRY)
 #undef REC_TRY
-  set_error("%s: no fused kernel instantiated for D=%d, n=%d (use rec_gather_concat_f32 + "
-            "rec_pairwise_dot_f32)", who, D, n);
-  return REC_ENOTIMPL;
+  {  // any other (D, n): generic LDS-staged kernel (correct for every shape the tile fits, not tuned)
+    const size_t lds = (size_t)4 * n * (D + 1) * sizeof(float);
+    REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: n=%d D=%d tile does not fit LDS", who, n, D);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pairdot_generic_gather_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      REC_CHECK_ARG(e == hipSuccess, REC_EHIP, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(pairdot_generic_gather_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, st, ts, F, ids,
+                       ids_dtype == REC_IDS_F32 ? 1 : 0, ids_stride, dense, dense_stride, B, D, out, out_stride,
+                       append_dense ? 1 : 0, oob_flag);
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
 }

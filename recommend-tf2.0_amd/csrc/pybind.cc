@@ -415,5 +415,82 @@ PYBIND11_MODULE(_C, m) {
                                P<float>(served), P<float>(rows_out), rows_cap, P<int32_t>(oob), P<void>(stream)),
           "rec_shard_lookup_f32");
   });
+  // ---- backward kernels ------------------------------------------------------------------------------------
+  m.def("transpose_f32", [](ptr_t x, int64_t M, int64_t N, int64_t xs, ptr_t out, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_transpose_f32(P<const float>(x), M, N, xs, P<float>(out), P<void>(stream)), "rec_transpose_f32");
+  });
+  m.def("act_grad_f32", [](ptr_t dy, int64_t dys, ptr_t y, int64_t ys, int64_t M, int64_t N, int act, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_act_grad_f32(P<float>(dy), dys, P<const float>(y), ys, M, N, act, P<void>(stream)), "rec_act_grad_f32");
+  });
+  m.def("colsum_workspace_bytes", [](int64_t M, int64_t N) { return rec_colsum_workspace_bytes(M, N); });
+  m.def("colsum_f32", [](ptr_t a, int64_t as, ptr_t b, int64_t bs, ptr_t rw, int64_t M, int64_t N, ptr_t out, ptr_t ws,
+                         ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_colsum_f32(P<const float>(a), as, P<const float>(b), bs, P<const float>(rw), M, N, P<float>(out), P<void>(ws),
+                         P<void>(stream)),
+          "rec_colsum_f32");
+  });
+  m.def("bn_train_f32", [](ptr_t x, int64_t xs, int64_t M, int64_t N, ptr_t gamma, ptr_t beta, float eps, float momentum,
+                           ptr_t mm, ptr_t mv, ptr_t y, int64_t ys, ptr_t save_mean, ptr_t save_inv, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_bn_train_f32(P<const float>(x), xs, M, N, P<const float>(gamma), P<const float>(beta), eps, momentum,
+                           P<float>(mm), P<float>(mv), P<float>(y), ys, P<float>(save_mean), P<float>(save_inv), P<void>(ws),
+                           P<void>(stream)),
+          "rec_bn_train_f32");
+  });
+  m.def("bn_train_grad_workspace_bytes", [](int64_t M, int64_t N) { return rec_bn_train_grad_workspace_bytes(M, N); });
+  m.def("bn_train_grad_f32", [](ptr_t x, int64_t xs, ptr_t dy, int64_t dys, int64_t M, int64_t N, ptr_t gamma, ptr_t save_mean,
+                                ptr_t save_inv, ptr_t dx, int64_t dxs, ptr_t dgamma, ptr_t dbeta, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_bn_train_grad_f32(P<const float>(x), xs, P<const float>(dy), dys, M, N, P<const float>(gamma),
+                                P<const float>(save_mean), P<const float>(save_inv), P<float>(dx), dxs, P<float>(dgamma),
+                                P<float>(dbeta), P<void>(ws), P<void>(stream)),
+          "rec_bn_train_grad_f32");
+  });
+  m.def("bce_sigmoid_grad_f32", [](ptr_t y, ptr_t p, int64_t n, float scale, ptr_t dz, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_bce_sigmoid_grad_f32(P<const float>(y), P<const float>(p), n, scale, P<float>(dz), P<void>(stream)),
+          "rec_bce_sigmoid_grad_f32");
+  });
+  m.def("gather_pairwise_dot_grad_f32", [](const std::vector<TableTuple>& tables, const std::vector<TableTuple>& grads,
+                                           ptr_t ids, int64_t ids_stride, ptr_t dense, int64_t dense_stride, int64_t B,
+                                           ptr_t dz, int64_t dz_stride, int append, ptr_t d_dense, int64_t dd_stride,
+                                           ptr_t stream) {
+    auto t = to_descs(tables), g = to_descs(grads);
+    py::gil_scoped_release nogil;
+    check(rec_gather_pairwise_dot_grad_f32(t.data(), g.data(), (int32_t)t.size(), P<const int32_t>(ids), ids_stride,
+                                           P<const float>(dense), dense_stride, B, P<const float>(dz), dz_stride, append,
+                                           P<float>(d_dense), dd_stride, P<void>(stream)),
+          "rec_gather_pairwise_dot_grad_f32");
+  });
+  m.def("fm_layer_grad_workspace_bytes", [](int64_t B, int64_t L1) { return rec_fm_layer_grad_workspace_bytes(B, L1); });
+  m.def("fm_layer_grad_f32", [](ptr_t first, int64_t fs, int64_t L1, ptr_t second, int64_t ss, int64_t M, ptr_t w, ptr_t dout,
+                                int64_t B, ptr_t d_first, int64_t dfs, ptr_t d_second, int64_t dss, ptr_t dw, ptr_t ws,
+                                ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_fm_layer_grad_f32(P<const float>(first), fs, L1, P<const float>(second), ss, M, P<const float>(w),
+                                P<const float>(dout), B, P<float>(d_first), dfs, P<float>(d_second), dss, P<float>(dw),
+                                P<void>(ws), P<void>(stream)),
+          "rec_fm_layer_grad_f32");
+  });
+  m.def("cross_layer_grad_f32", [](ptr_t x0, ptr_t xl, ptr_t w, int64_t dim, int64_t B, ptr_t g, ptr_t dx0, ptr_t ds,
+                                   ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_cross_layer_grad_f32(P<const float>(x0), P<const float>(xl), P<const float>(w), dim, B, P<float>(g),
+                                   P<float>(dx0), P<float>(ds), P<void>(stream)),
+          "rec_cross_layer_grad_f32");
+  });
+  m.def("adam_rows_f32", [](const std::vector<TableTuple>& var, const std::vector<TableTuple>& mm,
+                            const std::vector<TableTuple>& vv, const std::vector<TableTuple>& grad,
+                            const std::vector<TableTuple>& stamp, ptr_t ids, int64_t ids_stride, int64_t B, float lr, float b1,
+                            float b2, float eps, int64_t step, float l2, ptr_t stream) {
+    auto a = to_descs(var), b = to_descs(mm), c = to_descs(vv), d = to_descs(grad), e = to_descs(stamp);
+    py::gil_scoped_release nogil;
+    check(rec_adam_rows_f32(a.data(), b.data(), c.data(), d.data(), e.data(), (int32_t)a.size(), P<const int32_t>(ids),
+                            ids_stride, B, lr, b1, b2, eps, step, l2, P<void>(stream)),
+          "rec_adam_rows_f32");
+  });
 }
 

@@ -12,6 +12,7 @@ class DCN(Model):
                  dnn_dropout=0., embed_reg=1e-6, cross_w_reg=1e-6, cross_b_reg=1e-6):
         super().__init__()
         self.sparse_feature_columns = feature_columns
+        self.embed_reg = embed_reg
         self.layer_num = len(hidden_units)
         self.embed_layers = {
             'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(

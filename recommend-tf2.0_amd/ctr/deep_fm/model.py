@@ -15,6 +15,7 @@ class DeepFM(Model):
                  activation='relu', fm_w_reg=1e-6, embed_reg=1e-6):
         super().__init__()
         self.dense_feature_columns, self.sparse_feature_columns = feature_columns
+        self.embed_reg = embed_reg
         self.embed_layers = {
             'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
                 input_dim=feat['feat_num'], input_length=1, output_dim=feat['embed_dim'],

@@ -25,6 +25,7 @@ class DLRM(Model):
         if interaction not in ('cat', 'dot'):
             raise ValueError("interaction must be 'cat' or 'dot'")
         self.interaction = interaction
+        self.embed_reg = embed_reg
         self.dense_feature_columns, self.sparse_feature_columns = feature_columns
         self.embed_layers = {
             'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
