@@ -393,6 +393,15 @@ def main():
     if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.workload in ("dlrm_fused", "gather"):
         cpu_base = cpu_baseline(a, w)
 
+    # PCIe-inclusive rate (never `value`): raw tokens + raw dense features start in pinned HOST memory; the
+    # double-buffered feeder moves batch i+1 over PCIe and hashes / scales it on the device while batch i computes
+    pcie = None
+    if not a.no_side and world == 1 and a.workload == "dlrm_fused" and w.get("sharded") is None:
+        try:
+            pcie = pcie_inclusive(torch, dev, a, w, spin)
+        except Exception as e:  # noqa: BLE001
+            pcie = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     res = None
     if rank == 0:
         res = {
@@ -418,6 +427,8 @@ def main():
             res["gather_roofline"] = gather_roof
         if cpu_base is not None:
             res["cpu_baseline"] = cpu_base
+        if pcie is not None:
+            res["pcie_inclusive"] = pcie
 
     # At N > 1 the OTHER placement is measured in the same run and reported beside the headline.  It runs under a
     # watchdog: a collective that hangs must not cost the headline line (rank 0 prints what it has, every rank exits).
@@ -453,6 +464,35 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pcie_inclusive(torch, dev, a, w, spin):
+    from recamd import ops
+    from recamd.pipeline import BatchFeeder, MinMaxScaler
+    B, F = w["ids"][0].shape
+    nd, nb = 13, 48
+    V = w["shape_cfg"]["vocab"]
+    gen = torch.Generator().manual_seed(3)
+    tok = torch.randint(-2 ** 31, 2 ** 31 - 1, (nb * B, F), dtype=torch.int32, generator=gen).pin_memory()
+    raw = (torch.rand((nb * B, nd), generator=gen) * 1000).pin_memory()
+    sc = MinMaxScaler().fit(raw[:B].to(dev))
+    group = ops.TableGroup([w["arena"][f] for f in range(F)])
+    dense = w["dense"]
+    out = torch.empty((B, 480), dtype=torch.float32, device=dev)[:, :479]
+    feeder = BatchFeeder(raw, tok, B, scaler=sc, hash_vocab=[V] * F, device=dev)
+    for _d, ids in feeder:                      # untimed pass: pinned pages touched, clocks up
+        ops.gather_pairwise_dot(group, ids, dense, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _d, ids in feeder:
+        ops.gather_pairwise_dot(group, ids, dense, out=out)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    h2d = B * (F * 4 + nd * 4)
+    return {"value": round(nb * B / el, 1), "unit": "samples/s", "ms_per_step": round(el / nb * 1e3, 4), "steps": nb,
+            "h2d_bytes_per_step": h2d, "h2d_GBs": round(h2d * nb / el / 1e9, 2),
+            "path": "pinned host tokens (B,26) uint32 + raw dense (B,13) fp32 -> H2D on a copy stream -> rec_hash_ids_u32 + "
+                    "rec_minmax_scale_f32 on the device -> fused gather + pairwise dot; double-buffered (recamd.pipeline.BatchFeeder)"}
 
 
 def cpu_baseline(a, w):

@@ -337,6 +337,31 @@ int rec_adam_rows_f32(const rec_table_desc* var, const rec_table_desc* m, const 
                       int64_t ids_stride, int64_t B, float lr, float beta1, float beta2, float eps, int64_t step, float l2,
                       void* stream);
 
+/* ---- P1: the step before the path, on the device --------------------------------------------------
+ * Raw columns arrive over PCIe; these kernels turn them into what the models take.
+ * rec_label_encode_u32: sklearn LabelEncoder.transform of src/ctr/utils/data_process.py:66-68.  tokens (B, F) uint32
+ *   (Criteo's 8-digit hex categories; REC_TOKEN_MISSING = the "-1" of fillna('-1'), :63, which sorts first);
+ *   vocabs[f]: DEVICE pointer to column f's sorted (by that order) unique tokens, vocab_sizes[f] entries (the HOST
+ *   arrays `vocabs` / `vocab_sizes` are copied into the launch).  ids[b, f] = rank, or -1 and *unseen_flag = 1.
+ * rec_hash_ids_u32: id = mix32(token ^ mix32(seed, f)) mod vocab_sizes[f] (no vocabulary kept; not in the reference).
+ * rec_minmax_fit_f32 / rec_minmax_scale_f32: MinMaxScaler of :76-78, intended per-column form on astype(int) values
+ *   (truncate_to_int = 1): out = (trunc(x) - min) / (max - min), a constant column maps to 0.
+ * rec_pad_sequences_i32: tf.keras pad_sequences(maxlen) of src/match/utils/data_process.py:138 on a ragged batch
+ *   (values, offsets[B+1] int64): defaults pre_padding = 1, pre_truncating = 1, pad_value = 0. */
+#define REC_TOKEN_MISSING 0xffffffffu
+int rec_label_encode_u32(const uint32_t* const* vocabs /* host array of device ptrs */, const int32_t* vocab_sizes /* host */,
+                         int32_t F, const uint32_t* tokens, int64_t tok_stride, int64_t B, int32_t* ids, int64_t ids_stride,
+                         int32_t* unseen_flag, void* stream);
+int rec_hash_ids_u32(const uint32_t* tokens, int64_t tok_stride, const int32_t* vocab_sizes /* host */, int32_t F, int64_t B,
+                     uint32_t seed, int32_t* ids, int64_t ids_stride, void* stream);
+int64_t rec_minmax_workspace_bytes(int64_t M, int32_t N);
+int rec_minmax_fit_f32(const float* x, int64_t x_stride, int64_t M, int32_t N, int32_t truncate_to_int, float* col_min,
+                       float* col_max, void* workspace, void* stream);
+int rec_minmax_scale_f32(const float* x, int64_t x_stride, int64_t M, int32_t N, const float* col_min, const float* col_max,
+                         int32_t truncate_to_int, float* out, int64_t out_stride, void* stream);
+int rec_pad_sequences_i32(const int32_t* values, const int64_t* offsets, int64_t B, int32_t maxlen, int32_t pad_value,
+                          int32_t pre_padding, int32_t pre_truncating, int32_t* out, int64_t out_stride, void* stream);
+
 /* ---- C2: row-sharded lookup helpers (exchange itself = RCCL all-to-all issued by the host) --
  * Bucket a flat id list by owner rank for cyclic row sharding (owner = id % G, local = id / G):
  *   counts[g]      = number of ids owned by g             (device int32[G], zeroed by the call)

@@ -492,5 +492,42 @@ PYBIND11_MODULE(_C, m) {
                             ids_stride, B, lr, b1, b2, eps, step, l2, P<void>(stream)),
           "rec_adam_rows_f32");
   });
+  // ---- input pipeline --------------------------------------------------------------------------------------
+  m.def("label_encode_u32", [](const std::vector<ptr_t>& vocabs, const std::vector<int32_t>& sizes, ptr_t tokens,
+                               int64_t tok_stride, int64_t B, ptr_t ids, int64_t ids_stride, ptr_t unseen, ptr_t stream) {
+    std::vector<const uint32_t*> vp;
+    for (ptr_t v : vocabs) vp.push_back(P<const uint32_t>(v));
+    py::gil_scoped_release nogil;
+    check(rec_label_encode_u32(vp.data(), sizes.data(), (int32_t)vp.size(), P<const uint32_t>(tokens), tok_stride, B,
+                               P<int32_t>(ids), ids_stride, P<int32_t>(unseen), P<void>(stream)),
+          "rec_label_encode_u32");
+  });
+  m.def("hash_ids_u32", [](ptr_t tokens, int64_t tok_stride, const std::vector<int32_t>& sizes, int64_t B, uint32_t seed,
+                           ptr_t ids, int64_t ids_stride, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_hash_ids_u32(P<const uint32_t>(tokens), tok_stride, sizes.data(), (int32_t)sizes.size(), B, seed,
+                           P<int32_t>(ids), ids_stride, P<void>(stream)),
+          "rec_hash_ids_u32");
+  });
+  m.def("minmax_workspace_bytes", [](int64_t M, int N) { return rec_minmax_workspace_bytes(M, N); });
+  m.def("minmax_fit_f32", [](ptr_t x, int64_t xs, int64_t M, int N, int trunc, ptr_t mn, ptr_t mx, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_minmax_fit_f32(P<const float>(x), xs, M, N, trunc, P<float>(mn), P<float>(mx), P<void>(ws), P<void>(stream)),
+          "rec_minmax_fit_f32");
+  });
+  m.def("minmax_scale_f32", [](ptr_t x, int64_t xs, int64_t M, int N, ptr_t mn, ptr_t mx, int trunc, ptr_t out, int64_t os,
+                               ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_minmax_scale_f32(P<const float>(x), xs, M, N, P<const float>(mn), P<const float>(mx), trunc, P<float>(out), os,
+                               P<void>(stream)),
+          "rec_minmax_scale_f32");
+  });
+  m.def("pad_sequences_i32", [](ptr_t values, ptr_t offsets, int64_t B, int maxlen, int pad, int pre_pad, int pre_trunc,
+                                ptr_t out, int64_t os, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_pad_sequences_i32(P<const int32_t>(values), P<const int64_t>(offsets), B, maxlen, pad, pre_pad, pre_trunc,
+                                P<int32_t>(out), os, P<void>(stream)),
+          "rec_pad_sequences_i32");
+  });
 }
 
