@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void mha_ctr_kernel(const float* __restrict__ 
     const float* prow = Pm + ((size_t)h * N + i) * N;
     float acc = 0.f;
     for (int j = 0; j < N; ++j) acc = fmaf(prow[j], V[j * HS + c], acc);
-    if (W0) acc = fmaxf(acc + orow[e], 0.f);
+    if (W0) acc = relu_nan(acc + orow[e]);
     orow[e] = acc;
   }
 }
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) void mha_ctr_mfma_kernel(const float* __restri
           rr = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx, rr, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r] + act_apply(rr[r], act, 0.f), 0.f);
+        for (int r = 0; r < 4; ++r) o[r] = relu_nan(o[r] + act_apply(rr[r], act, 0.f));
       }
       const int qi = qt * 16 + lr;
       if (qi < N) *reinterpret_cast<f32x4*>(out + (b * N + qi) * (int64_t)HS + h * 16 + 4 * g) = o;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void mha_ctr_b3_kernel(const float* __restrict
       if (W0) {  // residual branch in the same (query on lane, dims in registers) layout
         const f32x4 rr = mfma6(w0, xf[qt], zero);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r] + act_apply(rr[r], act, 0.f), 0.f);
+        for (int r = 0; r < 4; ++r) o[r] = relu_nan(o[r] + act_apply(rr[r], act, 0.f));
       }
       const int qi = qt * 16 + lr;
       if (qi < N) *reinterpret_cast<f32x4*>(out + (b * N + qi) * (int64_t)HS + h * 16 + 4 * g) = o;

@@ -42,9 +42,12 @@ struct TableSet {
 };
 
 #ifdef __HIPCC__
+// tf.nn.relu propagates NaN (relu(NaN) = NaN); fmaxf(NaN, 0) would return 0 and hide a poisoned input
+__device__ __forceinline__ float relu_nan(float x) { return (x > 0.f || x != x) ? x : 0.f; }
+
 __device__ __forceinline__ float act_apply(float x, int act, float alpha) {
   switch (act) {
-    case REC_ACT_RELU: return fmaxf(x, 0.f);
+    case REC_ACT_RELU: return relu_nan(x);
     case REC_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
     case REC_ACT_TANH: return tanhf(x);
     case REC_ACT_PRELU: return x >= 0.f ? x : alpha * x;

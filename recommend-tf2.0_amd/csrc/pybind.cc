@@ -357,6 +357,17 @@ PYBIND11_MODULE(_C, m) {
     }
     return reinterpret_cast<ptr_t>(c);
   });
+  m.def("comm_from_nccl", [](ptr_t nccl_comm, int world, int rank) {   // borrow an existing ncclComm_t
+    rec_comm* c = nullptr;
+    check(rec_comm_from_nccl(&c, P<void>(nccl_comm), world, rank), "rec_comm_from_nccl");
+    return reinterpret_cast<ptr_t>(c);
+  });
+  // a transport struct built by another native module (address of a rec_transport); Python itself cannot supply callbacks
+  m.def("comm_create_with_transport", [](ptr_t transport, int world, int rank) {
+    rec_comm* c = nullptr;
+    check(rec_comm_create_with_transport(&c, P<const rec_transport>(transport), world, rank), "rec_comm_create_with_transport");
+    return reinterpret_cast<ptr_t>(c);
+  });
   m.def("comm_create_local", [](int world) {
     std::vector<rec_comm*> cs(world > 0 ? world : 0, nullptr);
     check(rec_comm_create_local(world, cs.data()), "rec_comm_create_local");

@@ -93,3 +93,37 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cc", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f"{f} references the oracle"
+
+
+@pytest.mark.gpu
+def test_integration_md_ctypes_stub_runs_on_the_gpu(dev):
+    """INTEGRATION.md §B is executable documentation: its ctypes stub (no torch types, no pybind11) is extracted from the
+    file, pointed at the built library and used to launch both entry points; results are checked against the oracle."""
+    import numpy as np
+    import torch
+    from oracle import ref_numpy as ref
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# recamd_ffi\.py.*?)```", md, flags=re.S)
+    assert m, "INTEGRATION.md lost its ctypes stub"
+    code = m.group(1).replace("/path/to/repo/recommend-tf2.0_amd/recamd/librecamd.so", LIB)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#recamd_ffi", "exec"), ns)
+    rng = np.random.default_rng(0)
+    F, V, D, B = 26, 50, 128, 300
+    tables = [rng.normal(size=(V, D)).astype(np.float32) for _ in range(F)]
+    ids = rng.integers(0, V, size=(B, F)).astype(np.int32)
+    dense = rng.normal(size=(B, D)).astype(np.float32)
+    tt = [torch.from_numpy(t).to(dev) for t in tables]
+    t_ids, t_dense = torch.from_numpy(ids).to(dev), torch.from_numpy(dense).to(dev)
+    out = torch.empty((B, F * D), dtype=torch.float32, device=dev)
+    ns["gather_concat"]([t.data_ptr() for t in tt], [V] * F, D, t_ids.data_ptr(), B, out.data_ptr())
+    width = (F + 1) * F // 2 + D
+    z = torch.empty((B, width), dtype=torch.float32, device=dev)
+    ns["dlrm_interaction"]([t.data_ptr() for t in tt], [V] * F, D, t_ids.data_ptr(), t_dense.data_ptr(), B, z.data_ptr())
+    torch.cuda.synchronize()
+    emb = ref.gather_concat(tables, ids)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), emb.view(np.uint32))
+    from tests.util import close_dot
+    X = np.concatenate([emb.reshape(B, F, D), dense[:, None, :]], axis=1)
+    assert close_dot(z.cpu().numpy()[:, :351], X)
+    assert np.array_equal(z.cpu().numpy()[:, 351:], dense)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import ref_numpy as ref
-from tests.util import close
+from tests.util import close, close_scaled
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,10 @@ def test_fm_layer(dev, B, L1, M):
     second = rng.normal(size=(B, M)).astype(np.float32) * 0.1
     w = (rng.normal(size=(L1, 1)) * 0.05).astype(np.float32)
     out = ops.fm_layer(T(first, dev), T(second, dev), T(w, dev)).cpu().numpy()
-    assert close(out, ref.fm_layer(first, second, w))
+    f64, s64 = first.astype(np.float64), second.astype(np.float64)
+    scale = np.sum(np.abs(f64) * np.abs(w.astype(np.float64)).reshape(1, -1)) + \
+        0.5 * (np.abs(s64).sum(1) ** 2 + (s64 ** 2).sum(1))[:, None]           # what each output is accumulated from
+    assert close_scaled(out, ref.fm_layer(first, second, w), scale)
 
 
 def test_fm_layer_kat_and_strided_concat(dev):
@@ -50,7 +53,12 @@ def test_cross_network(dev, B, dim, L):
     W = (rng.normal(size=(L, dim)) * 0.05).astype(np.float32)
     Bv = (rng.normal(size=(L, dim)) * 0.05).astype(np.float32)
     out = ops.cross_network(T(x, dev), T(W, dev), T(Bv, dev)).cpu().numpy()
-    assert close(out, ref.cross_network(x, W, Bv))
+    x64, scale = x.astype(np.float64), np.abs(x).astype(np.float64)
+    xl = x64
+    for l in range(L):   # |x0| (|x_l| . |w_l|) + |b_l| + the scale carried by x_l
+        scale = np.abs(x64) * (np.abs(xl) @ np.abs(W[l].astype(np.float64)))[:, None] + np.abs(Bv[l]) + scale
+        xl = x64 * (xl @ W[l].astype(np.float64))[:, None] + Bv[l] + xl
+    assert close_scaled(out, ref.cross_network(x, W, Bv), scale)
 
 
 def test_cross_kat_identity(dev):
