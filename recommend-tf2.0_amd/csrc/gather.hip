@@ -18,9 +18,14 @@
 //     8 TB/s.  Measured on MI355X (65 536 x 26 x 128, uniform ids): batches of 4 / 8 / 16 / 32 ->
 //     65.9 / 70.0 / 71.0 / 68.1 % of 8 TB/s; plain instead of nontemporal stores -> 63.4 %;
 //     nontemporal LOADS +0.2 % on uniform ids but they would bypass the caches that serve
-//     Zipf-distributed ids (83.8 % of peak), so loads stay plain.
+//     Zipf-distributed ids (83.8 % of peak), so loads stay plain.  Round 2: the same gather through a per-wave
+//     LDS-DMA ring with streaming loads (the transport that lifted the fused kernel from 0.59 to 0.71) is bit-exact
+//     and NOT faster here (322-325 us both, tools/exp/gather_variants/gather_ring.hip, tools/exp/gather_ab.py): with
+//     half of the traffic being the 872 MB output stream, the read path is not what bounds this kernel.
 //   * output stores are nontemporal: the 872 MB concat output is write-once and must not evict
 //     hot embedding rows from L2 / Infinity Cache (matters for Zipf-distributed ids).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rec {

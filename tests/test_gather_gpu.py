@@ -110,3 +110,29 @@ def test_cpu_tensor_fails_loudly():
     from recamd import ops
     with pytest.raises(RuntimeError):
         ops.TableGroup([torch.zeros(4, 4)])
+
+
+# ---- the LDS-DMA ring kernel (D = 128, int32 ids, plain concat output, >= 2048 rows) -----------------------------
+@pytest.mark.parametrize("B,F", [(79, 26), (80, 26), (1000, 26), (4099, 3), (2048, 1), (700, 5), (65, 33), (5000, 64)])
+def test_gather_ring_kernel_bit_exact(dev, B, F):
+    """chunks of 32 rows over persistent waves: batch sizes that leave a ragged last chunk, waves with unequal chunk
+    counts, out-of-range ids (zero rows + flag), fields > 32 (a chunk inside one sample)"""
+    from recamd import ops
+    rng = np.random.default_rng(B * 100 + F)
+    D = 128
+    vocabs = [int(v) for v in rng.integers(3, 200, size=F)]
+    tables = [rng.normal(size=(v, D)).astype(np.float32) for v in vocabs]
+    ids = np.stack([rng.integers(0, v, size=B) for v in vocabs], axis=1).astype(np.int32)
+    ids[B // 3, F // 2] = -1
+    ids[B - 1, F - 1] = vocabs[F - 1]
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables])
+    flag = ops.new_oob_flag(dev)
+    out = ops.gather_concat(g, torch.from_numpy(ids).to(dev), oob_flag=flag).cpu().numpy()
+    exp = ref.gather_concat(tables, ids, oob="zero")
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+    assert int(flag.item()) == 1
+    flag2 = ops.new_oob_flag(dev)
+    ids2 = np.clip(ids, 0, np.asarray(vocabs)[None, :] - 1).astype(np.int32)
+    out2 = ops.gather_concat(g, torch.from_numpy(ids2).to(dev), oob_flag=flag2).cpu().numpy()
+    assert np.array_equal(out2.view(np.uint32), ref.gather_concat(tables, ids2).view(np.uint32))
+    assert int(flag2.item()) == 0
