@@ -260,6 +260,15 @@ int rec_cosine_flat_f32(const float* a, const float* b, int64_t n, int32_t apply
 /* out[r, :] = x[r, :] * row_scale[r]:  `att_outputs *= mask`, src/match/sasrec/model.py:82 */
 int rec_scale_rows_f32(const float* x, const float* row_scale, int64_t rows, int32_t d, float* out,
                        void* stream);
+/* tf.concat([... , t, ...], axis=-1) for a tensor t no kernel of ours produced (raw dense inputs, ids fed as floats:
+ * src/ctr/din/model.py:64,68,81): dst[m, 0:N] = src[m, 0:N] at a column offset of a wider buffer; src_is_f32 = 0
+ * converts int32 values (the reference concatenates `item_sparse_input`, i.e. ids, as floats). */
+int rec_copy2d_f32(const void* src, int64_t src_stride, int32_t src_is_f32, int64_t M, int64_t N, float* dst,
+                   int64_t dst_stride, void* stream);
+/* AutoInt (intended form, SURVEY config 3): dense feature j joins the fields as x[b, j] * E[j, :]:
+ * out[b, j*D : (j+1)*D] = x[b, j] * E[j, :], written behind the gathered sparse fields of the same buffer. */
+int rec_scale_embed_f32(const float* x, int64_t x_stride, const float* E, int64_t B, int32_t nd, int32_t D, float* out,
+                        int64_t out_stride, void* stream);
 /* Dice, src/ctr/layers/modules.py:333-337 (inference): p = sigmoid((x - mean) * rsqrt(var + eps));
  * out = alpha * (1 - p) * x + p * x.  mean/var: (d) moving statistics or NULL (0 / 1);
  * alpha: device scalar. */

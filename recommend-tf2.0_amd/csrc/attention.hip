@@ -268,6 +268,120 @@ __global__ __launch_bounds__(256) void din_gather_pool_kernel(const float* __res
   if (on) reinterpret_cast<f32x4*>(out + b * d)[lane] = acc * (1.f / l);
 }
 
+// Same op, latency-restructured (round 2): the kernel above walks the slots with an id load -> address -> row load
+// chain per batch of 4 slots, i.e. two dependent memory latencies per batch (0.106 ms at config 4 = 0.40 of the HBM
+// roofline on the bytes it needs).  Here a wave first stages ALL ids of its sample in LDS (coalesced), compacts the
+// list of slots whose rows matter, and then streams the rows with the loads of batch i+1 in flight while batch i is
+// reduced (register double buffer): one memory latency per batch, hidden behind the previous batch's arithmetic.
+// Results are bit-identical to the streaming kernel (same per-slot arithmetic, same slot order).
+template <int IDS_F32, int U>
+__global__ __launch_bounds__(256) void din_gather_pool_lds_kernel(const float* __restrict__ q, DinTables tb, int n_tab,
+                                                                  int Dt, const void* __restrict__ ids,
+                                                                  const float* __restrict__ mask, int mask_mode,
+                                                                  const float* __restrict__ W,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ alpha, int act, int64_t B,
+                                                                  int T, float* __restrict__ out, int* __restrict__ oob) {
+  extern __shared__ int32_t din_lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  if (b >= B) return;
+  int32_t* sid = din_lds + (size_t)w * T * (n_tab + 1);   // [T][n_tab] ids of the sample
+  int32_t* slots = sid + (size_t)T * n_tab;                // [<= T] slots to fetch, in order; bit 31 = padded slot
+  const int d = n_tab * Dt;
+  const int nv = d >> 2;
+  const bool on = lane < nv;
+  const int lpt = Dt >> 2;
+  const int tab = on ? lane / lpt : 0;
+  const int col = on ? (lane - tab * lpt) * 4 : 0;
+  const float* tbase = tb.base[tab];
+  const uint32_t tvocab = (uint32_t)tb.vocab[tab];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t idbase = b * (int64_t)T * n_tab;
+  const int nid = T * n_tab;
+  bool bad = false;
+  for (int e = lane; e < nid; e += 64) {
+    const int32_t id = load_id<IDS_F32>(ids, idbase + e);
+    sid[e] = id;
+    const int c = e % n_tab;
+    bad = bad || (uint32_t)id >= (uint32_t)tb.vocab[c];
+  }
+  if (oob && bad) *oob = 1;
+  const f32x4 qv = on ? reinterpret_cast<const f32x4*>(q + b * d)[lane] : z4;
+  const f32x4 w1 = on ? reinterpret_cast<const f32x4*>(W)[lane] : z4;
+  const f32x4 w2 = on ? reinterpret_cast<const f32x4*>(W + d)[lane] : z4;
+  const f32x4 w3 = on ? reinterpret_cast<const f32x4*>(W + 2 * d)[lane] : z4;
+  const f32x4 w4 = on ? reinterpret_cast<const f32x4*>(W + 3 * d)[lane] : z4;
+  const f32x4 u = w2 - w3 + qv * w4;
+  const f32x4 cw = qv * (w1 + w3);
+  const float c0 = wave_sum(cw.x + cw.y + cw.z + cw.w) + bias[0];
+  const float al = alpha ? alpha[0] : 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto is_pad = [&](int t) -> bool {
+    if (mask_mode == 0) return true;
+    if (mask_mode == 1) return mask[b * T + t] == 0.f;
+    return sid[t * n_tab] == 0;
+  };
+  bool any_real = false;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    any_real = any_real || __any(t < T && !is_pad(t));
+  }
+  int n = 0;  // wave-uniform count of listed slots
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    const bool padl = t < T ? is_pad(t) : true;
+    const bool take = t < T && (!padl || !any_real);
+    const uint64_t m = __ballot(take);
+    if (take) slots[n + __popcll(m & ((1ull << lane) - 1ull))] = t | (padl ? (int)0x80000000 : 0);
+    n += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  auto load_batch = [&](int i0, f32x4 (&kr)[U]) {
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const int i = i0 + e < n ? i0 + e : (n > 0 ? n - 1 : 0);   // clamped: the load stays unconditional
+      const int t = n > 0 ? (slots[i] & 0x7fffffff) : 0;
+      const int32_t id = sid[t * n_tab + tab];
+      const bool ok = (uint32_t)id < tvocab;
+      const f32x4 row = *reinterpret_cast<const f32x4*>(tbase + (int64_t)(ok ? id : 0) * Dt + col);
+      kr[e] = (on && ok) ? row : z4;
+    }
+  };
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = z4;
+  auto reduce_batch = [&](int i0, const f32x4 (&kr)[U]) {
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      if (i0 + e >= n) break;  // wave-uniform
+      const f32x4 pr = kr[e] * u;
+      float s = wave_sum(pr.x + pr.y + pr.z + pr.w) + c0;
+      s = act_apply(s, act, al);
+      if (slots[i0 + e] < 0) s = kNegPad;
+      const float mn = fmaxf(m, s);
+      const float sc = expf(m - mn);
+      const float p = expf(s - mn);
+      acc = acc * sc + kr[e] * p;
+      l = l * sc + p;
+      m = mn;
+    }
+  };
+  f32x4 ka[U], kb[U];
+  load_batch(0, ka);
+  for (int i0 = 0; i0 < n; i0 += 2 * U) {
+    load_batch(i0 + U, kb);
+    reduce_batch(i0, ka);
+    load_batch(i0 + 2 * U, ka);
+    reduce_batch(i0 + U, kb);
+  }
+  if (on) reinterpret_cast<f32x4*>(out + b * d)[lane] = acc * (1.f / l);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K8 — match attention.  One workgroup per (sample, head, 256-query tile); the head's K and V
 // (Sk x dk each) are staged in LDS once per workgroup and read by broadcast (every thread reads
@@ -451,6 +565,23 @@ extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc
   const int mode = mask ? 1 : (mask_from_ids ? 2 : 0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+  // ids of a sample staged in LDS + pipelined row loads (din_gather_pool_lds_kernel) while the 4 waves' id lists fit
+  // 48 KiB; longer histories keep the streaming kernel.  REC_DIN_IMPL=stream (read once): A/B.
+  static const bool lds_ok = [] {
+    const char* e = getenv("REC_DIN_IMPL");
+    return !(e && e[0] == 's');
+  }();
+  const size_t lds = (size_t)4 * T * (n_tab + 1) * sizeof(int32_t);
+  if (lds_ok && lds <= 48 * 1024) {
+    if (ids_dtype == REC_IDS_F32)
+      hipLaunchKernelGGL((din_gather_pool_lds_kernel<1, 4>), grid, block, lds, st, q, tb, n_tab, Dt, ids, mask, mode, W,
+                         bias, alpha, act, B, T, out, oob_flag);
+    else
+      hipLaunchKernelGGL((din_gather_pool_lds_kernel<0, 4>), grid, block, lds, st, q, tb, n_tab, Dt, ids, mask, mode, W,
+                         bias, alpha, act, B, T, out, oob_flag);
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (ids_dtype == REC_IDS_F32)
     hipLaunchKernelGGL((din_gather_pool_kernel<1>), grid, block, 0, st, q, tb, n_tab, Dt, ids, mask, mode, W, bias,
                        alpha, act, B, T, out, oob_flag);

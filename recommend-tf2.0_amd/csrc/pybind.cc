@@ -540,5 +540,14 @@ PYBIND11_MODULE(_C, m) {
                                 P<int32_t>(out), os, P<void>(stream)),
           "rec_pad_sequences_i32");
   });
+  m.def("copy2d_f32", [](ptr_t src, int64_t ss, int is_f32, int64_t M, int64_t N, ptr_t dst, int64_t ds, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_copy2d_f32(P<const void>(src), ss, is_f32, M, N, P<float>(dst), ds, P<void>(stream)), "rec_copy2d_f32");
+  });
+  m.def("scale_embed_f32", [](ptr_t x, int64_t xs, ptr_t E, int64_t B, int nd, int D, ptr_t out, int64_t os, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_scale_embed_f32(P<const float>(x), xs, P<const float>(E), B, nd, D, P<float>(out), os, P<void>(stream)),
+          "rec_scale_embed_f32");
+  });
 }
 

@@ -788,6 +788,55 @@ extern "C" int rec_scale_rows_f32(const float* x, const float* row_scale, int64_
   return REC_OK;
 }
 
+// ---- concat helpers: tf.concat becomes "write at a column offset" also for tensors no kernel of ours produced ------
+namespace rec {
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int64_t ss, int src_f32,
+                                                     int64_t M, int64_t N, float* __restrict__ dst, int64_t ds) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N, n = i - m * N;
+  dst[m * ds + n] = src_f32 ? src[m * ss + n] : (float)reinterpret_cast<const int32_t*>(src)[m * ss + n];
+}
+// out[b, j * D + c] = x[b, j] * E[j, c]   (AutoInt's dense features as fields: value-scaled embedding rows)
+__global__ __launch_bounds__(256) void scale_embed_kernel(const float* __restrict__ x, int64_t xs,
+                                                          const float* __restrict__ E, int64_t B, int nd, int D,
+                                                          float* __restrict__ out, int64_t os) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)nd * D;
+  if (i >= B * per) return;
+  const int64_t b = i / per;
+  const int e = (int)(i - b * per);
+  out[b * os + e] = x[b * xs + e / D] * E[e];
+}
+}  // namespace rec
+
+extern "C" int rec_copy2d_f32(const void* src, int64_t src_stride, int32_t src_is_f32, int64_t M, int64_t N, float* dst,
+                              int64_t dst_stride, void* stream) {
+  const char* who = "rec_copy2d_f32";
+  REC_CHECK_ARG(M >= 0 && N >= 0 && src_stride >= N && dst_stride >= N, REC_ESHAPE, "%s: bad shape", who);
+  if (M * N == 0) return REC_OK;
+  REC_CHECK_ARG(src && dst, REC_EINVAL, "%s: NULL pointer", who);
+  hipLaunchKernelGGL(rec::copy2d_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), static_cast<const float*>(src), src_stride, src_is_f32, M, N,
+                     dst, dst_stride);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_scale_embed_f32(const float* x, int64_t x_stride, const float* E, int64_t B, int32_t nd, int32_t D,
+                                   float* out, int64_t out_stride, void* stream) {
+  const char* who = "rec_scale_embed_f32";
+  REC_CHECK_ARG(B >= 0 && nd >= 1 && D >= 1 && x_stride >= nd && out_stride >= (int64_t)nd * D, REC_ESHAPE,
+                "%s: bad shape", who);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(x && E && out, REC_EINVAL, "%s: NULL pointer", who);
+  const int64_t n = B * nd * D;
+  hipLaunchKernelGGL(rec::scale_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, x_stride, E, B, nd, D, out, out_stride);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
 extern "C" int rec_dice_f32(const float* x, const float* alpha, const float* mean, const float* var,
                             float eps, int64_t rows, int32_t d, float* out, void* stream) {
   const char* who = "rec_dice_f32";

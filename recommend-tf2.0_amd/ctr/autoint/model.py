@@ -56,6 +56,17 @@ class AutoInt(Model):
         dense_inputs = to_device_f32(dense_inputs, self.device)
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
         B, F = sparse_inputs.shape
+        if self.mode == 'intended' and self.embed_dense and len(set(self._group.dims)) == 1:
+            # fields of one sample = [26 looked-up rows | 13 value-scaled dense embeddings]: the gather and the scaling
+            # kernel write the two parts of ONE (B, (F + nd) * D) buffer (tf.concat as column offsets, no copy pass)
+            D = self._group.dims[0]
+            buf = torch.empty((B, (F + self.nd) * D), dtype=torch.float32, device=self.device)
+            ops.gather_concat(self._group, sparse_inputs, out=buf)                # :46
+            ops.scale_embed(dense_inputs, self._w['dense_embed'], buf[:, F * D:])
+            h = buf.view(B, F + self.nd, D)
+            for L in self.attention_layers:
+                h = L(h)
+            return ops.add_sigmoid(self.final_dense(h.reshape(B, -1)))            # :54-55
         sparse_embed = ops.gather_concat(self._group, sparse_inputs)               # :46
         if self.mode == 'as_written':
             x = torch.cat([sparse_embed, dense_inputs], dim=-1)                    # :48 (2-D!)

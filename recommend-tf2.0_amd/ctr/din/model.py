@@ -79,10 +79,24 @@ class DIN(Model):
         user_dense_input, user_sparse_input, item_dense_input, item_sparse_input, behavior_input = \
             [to_device_f32(t, self.device) for t in inputs]
         B = user_sparse_input.shape[0]
-        user_embeddings = ops.gather_concat(self._user_group, self._cols(user_sparse_input, self._user_cols))
-        user_embed = torch.cat([user_dense_input, user_embeddings], dim=-1)            # :62-64
-        item_embeddings = ops.gather_concat(self._item_group, self._cols(item_sparse_input, self._item_cols))
-        item_embed = torch.cat([item_sparse_input, item_embeddings], dim=-1)           # :66-68 (ids as floats)
+        # all_inputs = concat[user_dense, user_emb | item_sparse (ids as floats), item_emb | att] (:62-68, :81) lives in
+        # ONE buffer: every part is written at its column offset (gathers with out=, raw inputs with copy_cols)
+        nud, wu = user_dense_input.shape[1], self._user_group.width
+        nis, wi = item_sparse_input.shape[1], self._item_group.width
+        att_w = wi if self.mode == 'intended' else self.att_hidden_units
+        o_uemb, o_isp, o_iemb, o_att = nud, nud + wu, nud + wu + nis, nud + wu + nis + wi
+        total = o_att + att_w
+        all_buf = torch.empty((B, (total + 3) // 4 * 4), dtype=torch.float32, device=self.device)[:, :total]
+        ops.copy_cols(user_dense_input, all_buf)
+        user_embeddings = ops.gather_concat(self._user_group, self._cols(user_sparse_input, self._user_cols),
+                                            out=all_buf[:, o_uemb:o_uemb + wu])           # :62-64
+        ops.copy_cols(item_sparse_input, all_buf[:, o_isp:])                            # :68 (ids as floats)
+        # the item embeddings are also the attention query, which the pooling kernels want contiguous: gathered once
+        # into their own (B, wi) buffer and copied into the concat (6 MB at config 4)
+        item_embeddings = ops.gather_concat(self._item_group, self._cols(item_sparse_input, self._item_cols))  # :66-68
+        ops.copy_cols(item_embeddings, all_buf[:, o_iemb:])
+        self._all_buf, self._o_att = all_buf, o_att
+        user_embed = item_embed = None
         d_item = item_embeddings.shape[1]
         beh_ids = self._cols(behavior_input, self._beh_cols)
         if self.mode == 'intended' and self._beh_regular and self.fuse_history:
@@ -115,8 +129,9 @@ class DIN(Model):
         return self._head(user_embed, item_embed, att_outputs)
 
     def _head(self, user_embed, item_embed, att_outputs):
-        all_inputs = torch.cat([user_embed, item_embed, att_outputs], dim=-1)          # :81
-        x = all_inputs
+        ops.copy_cols(att_outputs if att_outputs.stride(1) == 1 else att_outputs.contiguous(),
+                      self._all_buf[:, self._o_att:])                                  # :81
+        x = self._all_buf
         for i, dense in enumerate(self.ffn):                                           # :83-87 (BN folded)
             if i == 0:
                 if not dense.built:

@@ -529,6 +529,31 @@ def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def copy_cols(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[:, :N] = src (a concat part written at a column offset: pass dst = buf[:, off:]); src fp32 or int32 (ids
+    concatenated as floats, src/ctr/din/model.py:68)."""
+    _chk(src, "src", None)
+    _chk(dst, "dst")
+    if src.dim() != 2 or dst.dim() != 2 or src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] != src.shape[0] or \
+            dst.shape[1] < src.shape[1] or src.dtype not in (torch.float32, torch.int32):
+        raise ValueError("copy_cols: expected 2-D fp32/int32 src and a 2-D fp32 dst view with at least as many columns")
+    C.copy2d_f32(src.data_ptr(), src.stride(0), 1 if src.dtype == torch.float32 else 0, src.shape[0], src.shape[1],
+                 dst.data_ptr(), dst.stride(0), _stream())
+    return dst
+
+
+def scale_embed(x: torch.Tensor, E: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[b, j*D:(j+1)*D] = x[b, j] * E[j]  (out: a (B, >= nd*D) view at the column offset of the concat buffer)"""
+    _rows2d(_chk(x, "x"), "x")
+    _chk(E, "E")
+    _chk(out, "out")
+    nd, D = E.shape
+    if x.shape[1] != nd or not E.is_contiguous() or out.shape[0] != x.shape[0] or out.shape[1] < nd * D or out.stride(1) != 1:
+        raise ValueError("scale_embed: inconsistent shapes")
+    C.scale_embed_f32(x.data_ptr(), x.stride(0), E.data_ptr(), x.shape[0], nd, D, out.data_ptr(), out.stride(0), _stream())
+    return out
+
+
 def dice(x: torch.Tensor, alpha: torch.Tensor, mean=None, var=None, eps: float = 1e-3) -> torch.Tensor:
     """Dice activation at inference (src/ctr/layers/modules.py:333-337)."""
     _chk(x, "x")
