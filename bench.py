@@ -42,6 +42,7 @@ for _p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BF16_DENSE_PEAK_TF = 2500.0    # dense bf16 MFMA peak; a bf16x3 product costs 6 MFMAs -> 416.7 TF fp32-equivalent
+F32_MFMA_PEAK_TF = 157.3       # dense fp32 MFMA peak (= the fp32 vector peak)
 NB = 8                         # distinct id batches rotated over the steps
 
 
@@ -175,12 +176,13 @@ def wl_autoint(torch, dev, a, rank, world):
     def step(i):
         m([dense, ids[i % NB]])
 
-    return {"step": step, "units": B, "work": B * flop, "dtype": "f32 (bf16x3 MFMA: exact 3-term bf16 split, fp32 accumulate)",
-            "bound": "mfma", "peak": round(BF16_DENSE_PEAK_TF / 6, 1), "unit": "TFLOP/s",
-            "kernel": "rec::mha_ctr_b3_kernel (3 launches) + gather + final Dense: whole forward", "pmc_key": None,
+    return {"step": step, "units": B, "work": B * flop, "dtype": "f32",
+            "bound": "mfma", "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "kernel": "rec::mha_ctr_stack_kernel<3, 1, 2, relu> (3 interacting layers in one launch, fp32 MFMA) + gather + "
+                      "dense-field embedding + final Dense/sigmoid: whole forward", "pmc_key": None,
             "workload": "AutoInt 39 fields dim 16, 3-layer 2-head self-attn, batch 4096 (BASELINE configs[2])",
             "config": {"batch_per_gpu": B, "global_batch": B * world, "fields": F + nd, "dim": D, "layers": 3, "heads": 2,
-                       "flop_per_sample": flop, "peak_note": "2.5 PFLOP/s dense bf16 / 6 MFMAs per fp32-equivalent product"},
+                       "flop_per_sample": flop, "peak_note": "157.3 TFLOP/s dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"},
             "side_gather": None, "shape_cfg": {}}
 
 

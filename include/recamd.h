@@ -179,6 +179,14 @@ int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv, int64_t B
                     int32_t din, const float* Wq, const float* Wk, const float* Wv,
                     const float* W0, int32_t H, int32_t S, int32_t act,
                     float* out, void* stream);
+/* L stacked interacting layers in ONE launch (AutoInt's `for layer in attention_layers`, BASELINE configs[2]): the
+ * output of layer l is the input of layer l + 1 and never leaves the registers; x (B, N, din) -> out (B, N, H*S).
+ * Wq/Wk/Wv/W0: HOST arrays of L device pointers (layer 0: (din, H*S), later layers: (H*S, H*S); W0 may be NULL or hold
+ * NULL entries = no residual).  Covered: S = 16, din in {16, 32}, H in {1, 2}, N <= 64, L <= 4; otherwise
+ * REC_ENOTIMPL (run rec_mha_ctr_f32 per layer).  fp32 MFMA: exact fp32 arithmetic. */
+int rec_mha_ctr_stack_f32(const float* x, int64_t B, int32_t N, int32_t din, const float* const* Wq,
+                          const float* const* Wk, const float* const* Wv, const float* const* W0, int32_t L, int32_t H,
+                          int32_t S, int32_t act, float* out, void* stream);
 
 /* ---- a9 / K7: DIN AttentionLayer pooling, src/ctr/layers/modules.py:144-175 ----------------
  * score[b,t] = act([q, k_t, q-k_t, q*k_t] . W + bias)  (Dense(hidden_unit=1)),

@@ -473,6 +473,41 @@ bool mha_ctr_b3_dispatch(const float* xq, const float* xk, const float* xv, int6
 
 using namespace rec;
 
+namespace rec {
+struct CtrStackArgs {
+  const float* Wq[4];
+  const float* Wk[4];
+  const float* Wv[4];
+  const float* W0[4];
+};
+bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const CtrStackArgs& wa, int L, int H, int S, int act,
+                            float* out, hipStream_t st);
+}  // namespace rec
+
+extern "C" int rec_mha_ctr_stack_f32(const float* x, int64_t B, int32_t N, int32_t din, const float* const* Wq,
+                                     const float* const* Wk, const float* const* Wv, const float* const* W0, int32_t L,
+                                     int32_t H, int32_t S, int32_t act, float* out, void* stream) {
+  using namespace rec;
+  const char* who = "rec_mha_ctr_stack_f32";
+  REC_CHECK_ARG(B >= 0 && N >= 1 && din >= 1 && H >= 1 && S >= 1 && L >= 1, REC_ESHAPE, "%s: bad shape", who);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_TANH, REC_EINVAL, "%s: bad act %d", who, act);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(x && Wq && Wk && Wv && out, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(L <= 4, REC_ENOTIMPL, "%s: at most 4 stacked layers per launch (got %d): split the stack", who, L);
+  CtrStackArgs wa{};
+  for (int l = 0; l < L; ++l) {
+    wa.Wq[l] = Wq[l], wa.Wk[l] = Wk[l], wa.Wv[l] = Wv[l];
+    wa.W0[l] = W0 ? W0[l] : nullptr;
+  }
+  if (!mha_ctr_stack_dispatch(x, B, N, din, wa, L, H, S, act, out, reinterpret_cast<hipStream_t>(stream))) {
+    set_error("%s: stack not covered (needs S = 16, din in {16, 32}, H in {1, 2}, N <= 64, aligned x / out): run the "
+              "layers one by one with rec_mha_ctr_f32", who);
+    return REC_ENOTIMPL;
+  }
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
 extern "C" int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv, int64_t B,
                                int32_t N, int32_t din, const float* Wq, const float* Wk,
                                const float* Wv, const float* W0, int32_t H, int32_t S, int32_t act,
@@ -483,7 +518,7 @@ extern "C" int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv
   if (B == 0) return REC_OK;
   REC_CHECK_ARG(xq && xk && xv && Wq && Wk && Wv && out, REC_EINVAL, "%s: NULL pointer", who);
   {
-    // default: bf16x3 kernel (attention_ctr_b3.hip) for the AutoInt shapes; REC_MHA_IMPL = "f32" keeps the fp32-MFMA
+    // default: bf16x3 kernel (attention_ctr.hip) for the AutoInt shapes; REC_MHA_IMPL = "f32" keeps the fp32-MFMA
     // kernel, "valu" the LDS/VALU kernel (A/B only)
     const char* e = getenv("REC_MHA_IMPL");
     if (!(e && (e[0] == 'v' || e[0] == 'f')) && mha_ctr_b3_dispatch(xq, xk, xv, B, N, din, Wq, Wk, Wv, W0, H, S, act, out,

@@ -549,5 +549,21 @@ PYBIND11_MODULE(_C, m) {
     check(rec_scale_embed_f32(P<const float>(x), xs, P<const float>(E), B, nd, D, P<float>(out), os, P<void>(stream)),
           "rec_scale_embed_f32");
   });
+  m.def("mha_ctr_stack_f32", [](ptr_t x, int64_t B, int N, int din, const std::vector<ptr_t>& Wq, const std::vector<ptr_t>& Wk,
+                                const std::vector<ptr_t>& Wv, const std::vector<ptr_t>& W0, int H, int S, int act, ptr_t out,
+                                ptr_t stream) {
+    const size_t L = Wq.size();
+    if (Wk.size() != L || Wv.size() != L || (!W0.empty() && W0.size() != L))
+      throw std::runtime_error("mha_ctr_stack_f32: weight lists must have one entry per layer");
+    std::vector<const float*> q, k, v, r;
+    for (size_t l = 0; l < L; ++l) {
+      q.push_back(P<const float>(Wq[l])), k.push_back(P<const float>(Wk[l])), v.push_back(P<const float>(Wv[l]));
+      r.push_back(W0.empty() ? nullptr : P<const float>(W0[l]));
+    }
+    py::gil_scoped_release nogil;
+    check(rec_mha_ctr_stack_f32(P<const float>(x), B, N, din, q.data(), k.data(), v.data(), r.data(), (int32_t)L, H, S, act,
+                                P<float>(out), P<void>(stream)),
+          "rec_mha_ctr_stack_f32");
+  });
 }
 

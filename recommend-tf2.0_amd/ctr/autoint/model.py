@@ -51,6 +51,32 @@ class AutoInt(Model):
         self.final_dense = nn.Dense(1, activation=None)
         self._eye = None
 
+    def _head(self, flat):
+        """sigmoid(Dense(1)(flat)) in ONE launch (the Dense kernel's fused activation)"""
+        fd = self.final_dense
+        if not fd.built:
+            fd.build(flat.shape[-1])
+        return ops.dense(flat, fd._w['kernel'], fd._w.get('bias'), 'sigmoid')
+
+    def _interact(self, h):
+        """the stacked interacting layers: ONE launch when the fused stack kernel covers them (activations stay in
+        registers between layers), else layer by layer"""
+        layers = self.attention_layers
+        hs = layers[0]._head_num * layers[0]._head_size
+        for i, L in enumerate(layers):
+            if not L.built:
+                L.build(h.shape[-1] if i == 0 else hs)
+        same = all(L._head_num == layers[0]._head_num and L._head_size == layers[0]._head_size and
+                   L._activation == layers[0]._activation for L in layers)
+        if same and isinstance(layers[0]._activation, (str, type(None))):
+            out = ops.mha_ctr_stack(h.contiguous(), [(L._w['Wq'], L._w['Wk'], L._w['Wv'], L._w.get('W0')) for L in layers],
+                                    layers[0]._head_num, layers[0]._head_size, layers[0]._activation)
+            if out is not None:
+                return out
+        for L in layers:
+            h = L(h)
+        return h
+
     def call(self, inputs, **kwargs):
         dense_inputs, sparse_inputs = inputs
         dense_inputs = to_device_f32(dense_inputs, self.device)
@@ -63,10 +89,8 @@ class AutoInt(Model):
             buf = torch.empty((B, (F + self.nd) * D), dtype=torch.float32, device=self.device)
             ops.gather_concat(self._group, sparse_inputs, out=buf)                # :46
             ops.scale_embed(dense_inputs, self._w['dense_embed'], buf[:, F * D:])
-            h = buf.view(B, F + self.nd, D)
-            for L in self.attention_layers:
-                h = L(h)
-            return ops.add_sigmoid(self.final_dense(h.reshape(B, -1)))            # :54-55
+            h = self._interact(buf.view(B, F + self.nd, D))
+            return self._head(h.reshape(B, -1))                                   # :54-55
         sparse_embed = ops.gather_concat(self._group, sparse_inputs)               # :46
         if self.mode == 'as_written':
             x = torch.cat([sparse_embed, dense_inputs], dim=-1)                    # :48 (2-D!)
@@ -90,7 +114,6 @@ class AutoInt(Model):
             h = sparse_embed.view(B, F, D)
             if self.embed_dense:
                 h = torch.cat([h, dense_inputs[:, :, None] * self._w['dense_embed'][None]], dim=1).contiguous()
-            for L in self.attention_layers:
-                h = L(h)
+            h = self._interact(h)
             flat = h.reshape(B, -1)
-        return ops.add_sigmoid(self.final_dense(flat))                             # :54-55
+        return self._head(flat)                                                    # :54-55

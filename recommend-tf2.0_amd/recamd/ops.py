@@ -296,6 +296,34 @@ def mha_ctr(xq: torch.Tensor, xk: torch.Tensor, xv: torch.Tensor, Wq, Wk, Wv, W0
     return out
 
 
+def mha_ctr_stack(x: torch.Tensor, layers, head_num: int, head_size: int, act="relu") -> Optional[torch.Tensor]:
+    """Stacked ctr MultiHeadAttention layers (one input tensor each) in ONE launch: layers = [(Wq, Wk, Wv, W0|None), ...].
+    Returns None when the stack is not covered by the fused kernel (the caller then applies the layers one by one)."""
+    _chk(x, "x")
+    if x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("x: expected contiguous (B, N, din)")
+    B, N, din = x.shape
+    HS = head_num * head_size
+    L = len(layers)
+    if head_size != 16 or din not in (16, 32) or head_num not in (1, 2) or N > 64 or not 1 <= L <= 4:
+        return None
+    has_res = [w[3] is not None for w in layers]
+    for l, (wq, wk, wv, w0) in enumerate(layers):
+        kin = din if l == 0 else HS
+        for t in (wq, wk, wv) + ((w0,) if w0 is not None else ()):
+            _chk(t, "W")
+            if tuple(t.shape) != (kin, HS) or not t.is_contiguous():
+                return None
+    if any(has_res) and not all(has_res):
+        w0s = [w[3].data_ptr() if w[3] is not None else 0 for w in layers]
+    else:
+        w0s = [w[3].data_ptr() for w in layers] if all(has_res) else []
+    out = torch.empty((B, N, HS), dtype=torch.float32, device=x.device)
+    C.mha_ctr_stack_f32(x.data_ptr(), B, N, din, [w[0].data_ptr() for w in layers], [w[1].data_ptr() for w in layers],
+                        [w[2].data_ptr() for w in layers], w0s, head_num, head_size, _act_id(act), out.data_ptr(), _stream())
+    return out
+
+
 def din_attention_pool(q, k, v, mask, W, bias, act="sigmoid", alpha=None) -> torch.Tensor:
     """DIN AttentionLayer (src/ctr/layers/modules.py:144-175), hidden_unit = 1.
     q (B,d); k,v (B,T,d); mask (B,T) float tensor or None (None => uniform, modules.py:164-165)."""

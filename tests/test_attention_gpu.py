@@ -209,3 +209,30 @@ def test_gather_mha_fewq_matches_unfused(dev, B, Sq, Sk, d, H, fids):
     exp = ops.mha_rowmask(q, x, x, mask, H)
     got = ops.gather_mha_fewq(q, table, ids, mask, H)
     assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize("N,din,H,L,use_res", [(39, 16, 2, 3, True), (39, 16, 2, 1, False), (16, 32, 1, 2, True),
+                                               (64, 16, 2, 4, True), (7, 32, 2, 2, False), (23, 16, 1, 3, True)])
+@pytest.mark.parametrize("B", [1, 5, 4100])
+def test_mha_ctr_stack_matches_layerwise_oracle(dev, N, din, H, L, use_res, B):
+    """L stacked interacting layers in one launch (activations stay in registers) == the oracle applied layer by layer;
+    B = 4100 exceeds one sample per wave on a 256-CU part, so waves loop over several samples."""
+    from recamd import ops
+    rng = np.random.default_rng(N + din + L + B)
+    S = 16
+    hs = H * S
+    x = (rng.normal(size=(B, N, din)) * 0.5).astype(np.float32)
+    layers = []
+    for l in range(L):
+        kin = din if l == 0 else hs
+        layers.append([(rng.normal(size=(kin, hs)) / np.sqrt(kin)).astype(np.float32) for _ in range(4 if use_res else 3)] +
+                      ([] if use_res else [None]))
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)  # noqa: E731
+    out = ops.mha_ctr_stack(t(x), [tuple(t(w) for w in lw) for lw in layers], H, S, "relu")
+    assert out is not None
+    nb = min(B, 64)                                        # the fp64 oracle on a slice of the batch (first and last)
+    sel = np.r_[0:nb // 2 + 1, B - nb // 2:B] if B > nb else np.arange(B)
+    exp = x.astype(np.float64)[sel]
+    for lw in layers:
+        exp = ref.mha_ctr(exp, exp, exp, lw[0], lw[1], lw[2], lw[3], H, S, "relu")
+    assert close(out.cpu().numpy()[sel], exp)
