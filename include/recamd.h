@@ -232,6 +232,36 @@ int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const fl
                         int64_t B, int32_t Sq, int32_t Sk, int32_t dm, int32_t H, float* out,
                         void* stream);
 
+/* ---- SASRec forward with ONE encoder block, one head, last position only — in one launch -----------------
+ * src/match/sasrec/model.py:72-96 (mask :72, seq lookup * mask :75,:81-82, the encoder block of
+ * src/match/layers/modules.py:152-185, seq_info = att_outputs[:, -1] :88, pos / neg lookups and logits :77-79,:88-96).
+ * Only x[:, -1] of the block is consumed, so only that query row is encoded (exact), against all S keys.
+ * rec_sasrec_block: the block's weights in their Keras layouts — wq / wk / wv (d, d) (in, out) with biases (bk never
+ * influences the softmax and is not read), LayerNormalization gamma / beta, the two k=1 Conv1D kernels as (d, ffn)
+ * and (ffn, d).
+ * seq_ids (B, S) int32: a slot whose id equals pad_id, or lies outside [0, seq_vocab), is a ZERO row (the reference
+ * multiplies pad rows by mask = 0); out-of-range ids other than pad_id also raise *oob_flag.  The query / output mask
+ * of sample b is mask_ids[b * mask_stride] != 0 (pass seq_ids + S - 1 with stride seq_ids_stride for the reference's
+ * `seq != 0`).  Candidates: n_pos ids from pos_table then n_neg ids from neg_table (the reference's three DIFFERENT
+ * tables); logits[b, j] = candidate_j . seq_info[b], j < n_pos + n_neg.  seq_info (B, d) may be NULL.
+ * This kernel: d = 64, ffn_hidden in {64, 128}, S <= ~600 (LDS); other shapes return REC_ENOTIMPL and the caller
+ * composes rec_gather_mha_fewq_f32 / rec_dense_f32 / rec_layernorm_residual_f32 / rec_gather_dot_scores_f32. */
+typedef struct rec_sasrec_block {
+  const float *wq, *bq, *wk, *wv, *bv;
+  const float *ln1_gamma, *ln1_beta;
+  const float *w1, *b1, *w2, *b2;
+  const float *ln2_gamma, *ln2_beta;
+  float ln1_eps, ln2_eps;
+  int32_t ffn_hidden;
+} rec_sasrec_block;
+int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
+                            const int32_t* seq_ids, int64_t seq_ids_stride, int32_t S, int32_t pad_id,
+                            const int32_t* mask_ids, int64_t mask_stride, const float* pos_table, int32_t pos_vocab,
+                            const int32_t* pos_ids, int64_t pos_ids_stride, int32_t n_pos, const float* neg_table,
+                            int32_t neg_vocab, const int32_t* neg_ids, int64_t neg_ids_stride, int32_t n_neg, int64_t B,
+                            int32_t d, float* seq_info, float* logits, int64_t logits_stride, int32_t* oob_flag,
+                            void* stream);
+
 /* ---- a13 / K9: LayerNormalization(x + r) [* mask], src/match/layers/modules.py:173-185 -----
  * y = LN(x + r) * gamma + beta over the last axis (biased variance, eps); r may be NULL;
  * if row_mask != NULL each output row is multiplied by row_mask[row]

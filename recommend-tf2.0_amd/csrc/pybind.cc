@@ -565,5 +565,24 @@ PYBIND11_MODULE(_C, m) {
                                 P<float>(out), P<void>(stream)),
           "rec_mha_ctr_stack_f32");
   });
+  m.def("sasrec_last_row_f32", [](const std::vector<ptr_t>& w, float eps1, float eps2, int ffn_hidden, ptr_t seq_table,
+                                  int seq_vocab, ptr_t seq_ids, int64_t seq_stride, int S, int pad_id, ptr_t mask_ids,
+                                  int64_t mask_stride, ptr_t pos_table, int pos_vocab, ptr_t pos_ids, int64_t pos_stride,
+                                  int n_pos, ptr_t neg_table, int neg_vocab, ptr_t neg_ids, int64_t neg_stride, int n_neg,
+                                  int64_t B, int d, ptr_t seq_info, ptr_t logits, int64_t logits_stride, ptr_t oob,
+                                  ptr_t stream) {
+    if (w.size() != 13) throw std::runtime_error("sasrec_last_row_f32: 13 weight pointers expected");
+    rec_sasrec_block blk{P<const float>(w[0]), P<const float>(w[1]), P<const float>(w[2]), P<const float>(w[3]),
+                         P<const float>(w[4]), P<const float>(w[5]), P<const float>(w[6]), P<const float>(w[7]),
+                         P<const float>(w[8]), P<const float>(w[9]), P<const float>(w[10]), P<const float>(w[11]),
+                         P<const float>(w[12]), eps1, eps2, ffn_hidden};
+    py::gil_scoped_release nogil;
+    check(rec_sasrec_last_row_f32(&blk, P<const float>(seq_table), seq_vocab, P<const int32_t>(seq_ids), seq_stride, S,
+                                  pad_id, P<const int32_t>(mask_ids), mask_stride, P<const float>(pos_table), pos_vocab,
+                                  P<const int32_t>(pos_ids), pos_stride, n_pos, P<const float>(neg_table), neg_vocab,
+                                  P<const int32_t>(neg_ids), neg_stride, n_neg, B, d, P<float>(seq_info), P<float>(logits),
+                                  logits_stride, P<int32_t>(oob), P<void>(stream)),
+          "rec_sasrec_last_row_f32");
+  });
 }
 

@@ -1,0 +1,399 @@
+// SASRec forward, one encoder block, last position only, in ONE launch (BASELINE configs[4]).
+//
+// What it replaces (src/match/sasrec/model.py:72-96 with blocks = 1, num_heads = 1; the encoder block is
+// src/match/layers/modules.py:152-185, its attention :76-131, its FFN :134-149):
+//     mask        = seq != 0                                      :72
+//     seq_embed   = Embedding_seq(seq) * mask                     :75, :81-82
+//     att         = softmax(wq(x) wk(x)^T / sqrt(d)) wv(x)        (query rows masked, keys never)
+//     out1        = LN1(x + att);  out2 = LN2(out1 + FFN(out1));  att_outputs = out2 * mask       :85-86
+//     seq_info    = att_outputs[:, -1]                            :88
+//     logits      = [Embedding_pos(pos) . seq_info, Embedding_neg(neg) . seq_info]                :77-79, :88-96
+// Only the LAST position of the block is consumed, so only that query row is encoded (exact), and with one head
+// the K / V projections of the S positions fold away (exact algebra, see match/layers/modules.py in this repo):
+//     q . (x_j Wk + bk) = x_j . (Wk q) + const,     sum_j p_j (x_j Wv + bv) = (sum_j p_j x_j) Wv + bv.
+// Round 2 profile of the unfused path at B = 8192, S = 200, d = 64, 100 negatives: two HBM-bound kernels (~85 us)
+// inside a 234-us forward made of ~10 short launches + ~8 elementwise launches.  Here one wave owns a sample from
+// its ids to its logits: last-row lookup -> Wq -> Wk^T pull-back -> attention over the raw item rows fetched by
+// id (pad / out-of-range slots are zero rows: not fetched, counted into the softmax denominator) -> Wv -> LN1 ->
+// FFN -> LN2 * mask -> the 1 + n candidate rows fetched by id and dotted.  Bytes from HBM = the rows of the real
+// slots + the candidate rows + the ids: nothing else is read or written (logits and seq_info excepted).
+//
+// Layout: a vector of d = 64 elements lives one element per lane.  The block's weights (112 KiB at ffn = 128) are
+// staged once per workgroup into LDS in their Keras (in, out) layout — lane o reads W[i][o], conflict-free — Wk
+// transposed with a padded stride; a workgroup is 16 waves (one per CU: the weights take most of the LDS) that
+// walk the samples persistently and never synchronise again.  Row fetches use 16 lanes per 256-B row (16 B each),
+// 4 rows per wave instruction, 8 instructions (8 KiB) in flight per wave.
+#include "common.h"
+
+namespace rec {
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 64;       // d_model
+constexpr int kWaves = 16;   // per workgroup
+constexpr int kU = 8;        // row-load instructions in flight per wave (4 rows each)
+
+struct SasrecParams {
+  const float *wq, *bq, *wk, *wv, *bv, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
+  float eps1, eps2;
+  int fh;  // FFN hidden width: 64 or 128
+};
+
+__device__ __forceinline__ float bcast(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// y[lane] = sum_i x_i W[i][col], x one element per lane, W in LDS with row stride `ld`; four partial sums
+// (the column index is laundered through an empty asm: the weights do not depend on the sample, and without it the
+// compiler hoists all 28 672 / 64 weight reads out of the persistent loop and spills them)
+template <int LD>
+__device__ __forceinline__ float matvec64(const float* __restrict__ W, float x, int col, float init) {
+  asm volatile("" : "+v"(col));
+  float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; i += 4) {
+    a0 = fmaf(bcast(x, i), W[(i)*LD + col], a0);
+    a1 = fmaf(bcast(x, i + 1), W[(i + 1) * LD + col], a1);
+    a2 = fmaf(bcast(x, i + 2), W[(i + 2) * LD + col], a2);
+    a3 = fmaf(bcast(x, i + 3), W[(i + 3) * LD + col], a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+__device__ __forceinline__ float layer_norm64(float v, float g, float b, float eps) {
+  const float mu = wave_sum(v) * (1.f / 64.f);
+  const float c = v - mu;
+  const float var = wave_sum(c * c) * (1.f / 64.f);
+  return c * (1.f / sqrtf(var + eps)) * g + b;
+}
+
+__device__ __forceinline__ float group16_sum(float s) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+template <int FH>
+__global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
+    SasrecParams P, const float* __restrict__ seq_table, int32_t seq_vocab, const int32_t* __restrict__ seq_ids,
+    int64_t seq_stride, int S, int32_t pad_id, const int32_t* __restrict__ mask_ids, int64_t mask_stride,
+    const float* __restrict__ pos_table, int32_t pos_vocab, const int32_t* __restrict__ pos_ids, int64_t pos_stride,
+    int n_pos, const float* __restrict__ neg_table, int32_t neg_vocab, const int32_t* __restrict__ neg_ids,
+    int64_t neg_stride, int n_neg, int64_t B, float* __restrict__ seq_info, float* __restrict__ logits,
+    int64_t logits_stride, int* __restrict__ oob, int lst_cap) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LDK = 65;                       // padded row stride of Wk^T
+  float* const Wq = lds;                        // [64][64]   (in, out)
+  float* const WkT = Wq + 64 * 64;              // [64 out][65]: WkT[o][i] = Wk[i][o]
+  float* const Wv = WkT + 64 * LDK + 60;        // keep 16-B alignment (64*65 + 60 = 4220 = 4 * 1055)
+  float* const W1 = Wv + 64 * 64;               // [64][FH]
+  float* const W2 = W1 + 64 * FH;               // [FH][64]
+  float* const vec = W2 + FH * 64;              // bq bv g1 be1 b2 g2 be2 (64 each), b1 (FH)
+  int32_t* const lst_all = reinterpret_cast<int32_t*>(vec + 7 * 64 + FH);
+  const int tid = threadIdx.x;
+  for (int e = tid * 4; e < 64 * 64; e += kWaves * 64 * 4) {
+    *reinterpret_cast<f32x4*>(Wq + e) = *reinterpret_cast<const f32x4*>(P.wq + e);
+    *reinterpret_cast<f32x4*>(Wv + e) = *reinterpret_cast<const f32x4*>(P.wv + e);
+  }
+  for (int e = tid; e < 64 * 64; e += kWaves * 64) WkT[(e & 63) * LDK + (e >> 6)] = P.wk[e];   // e = i * 64 + o
+  for (int e = tid * 4; e < 64 * FH; e += kWaves * 64 * 4) {
+    *reinterpret_cast<f32x4*>(W1 + e) = *reinterpret_cast<const f32x4*>(P.w1 + e);
+    *reinterpret_cast<f32x4*>(W2 + e) = *reinterpret_cast<const f32x4*>(P.w2 + e);
+  }
+  if (tid < 64) {
+    vec[tid] = P.bq[tid];
+    vec[64 + tid] = P.bv[tid];
+    vec[128 + tid] = P.g1[tid];
+    vec[192 + tid] = P.be1[tid];
+    vec[256 + tid] = P.b2[tid];
+    vec[320 + tid] = P.g2[tid];
+    vec[384 + tid] = P.be2[tid];
+  }
+  if (tid < FH) vec[448 + tid] = P.b1[tid];
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
+  int32_t* const lst = lst_all + wave * lst_cap;
+  const float scale_log2e = 1.4426950408889634f * 0.125f;   // log2(e) / sqrt(64)
+  const int n_cand = n_pos + n_neg;
+
+  for (int64_t b = (int64_t)blockIdx.x * kWaves + wave; b < B; b += (int64_t)gridDim.x * kWaves) {
+    // ---- compacted list of the slots that hold a real row; everything else is a zero row ----------------------
+    const int32_t* ids_b = seq_ids + b * seq_stride;
+    int nr = 0;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+      const int j = j0 + lane;
+      const int32_t id = j < S ? ids_b[j] : pad_id;
+      const bool is_pad = id == pad_id || j >= S;
+      const bool ok = !is_pad && (uint32_t)id < (uint32_t)seq_vocab;
+      if (!ok && !is_pad && oob) *oob = 1;
+      const uint64_t bal = __ballot(ok);
+      if (ok) lst[nr + __popcll(bal & ((1ull << lane) - 1ull))] = id;
+      nr += __popcll(bal);
+    }
+    const int32_t id_last = ids_b[S - 1];
+    const bool last_ok = id_last != pad_id && (uint32_t)id_last < (uint32_t)seq_vocab;
+    const float mask_last = mask_ids[b * mask_stride] != 0 ? 1.f : 0.f;
+    // ---- last position: x -> q = x Wq + bq -> q_back = Wk q ---------------------------------------------------
+    float x_last = seq_table[(int64_t)(last_ok ? id_last : 0) * kD + lane];
+    x_last = last_ok ? x_last : 0.f;
+    const float q = matvec64<64>(Wq, x_last, lane, vec[lane]);
+    const float q_back = matvec64<LDK>(WkT, q, lane, 0.f);
+    f32x4 qv;
+    qv.x = __shfl(q_back, sub * 4, 64);
+    qv.y = __shfl(q_back, sub * 4 + 1, 64);
+    qv.z = __shfl(q_back, sub * 4 + 2, 64);
+    qv.w = __shfl(q_back, sub * 4 + 3, 64);
+    // ---- attention over the raw rows of the real slots (online softmax per 16-lane group) ---------------------
+    const bool masked = mask_last == 0.f;      // masked query row: all logits equal -> uniform over all S keys
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* tb = seq_table + sub * 4;
+    for (int r0 = 0; r0 < nr; r0 += 4 * kU) {
+      // two halves of kU/2 load instructions; the second one only when it holds a real row (wave-uniform test).  Rows
+      // past the end re-read the last real row (a cache hit) and enter the softmax with the logit -inf (weight 0).
+      f32x4 kr[kU];
+      float s[kU];
+      const bool second = r0 + 2 * kU < nr;
+#pragma unroll
+      for (int u = 0; u < kU / 2; ++u) {
+        const int r = r0 + 4 * u + grp;
+        kr[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr - 1] * kD);
+      }
+      if (second) {
+#pragma unroll
+        for (int u = kU / 2; u < kU; ++u) {
+          const int r = r0 + 4 * u + grp;
+          kr[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr - 1] * kD);
+        }
+      }
+      float mb = m;
+#pragma unroll
+      for (int u = 0; u < kU / 2; ++u) {
+        const f32x4 pr = kr[u] * qv;
+        float d = group16_sum((pr.x + pr.y) + (pr.z + pr.w));
+        d = masked ? 0.f : d * scale_log2e;
+        s[u] = (r0 + 4 * u + grp < nr) ? d : -INFINITY;
+        mb = fmaxf(mb, s[u]);
+      }
+      if (second) {
+#pragma unroll
+        for (int u = kU / 2; u < kU; ++u) {
+          const f32x4 pr = kr[u] * qv;
+          float d = group16_sum((pr.x + pr.y) + (pr.z + pr.w));
+          d = masked ? 0.f : d * scale_log2e;
+          s[u] = (r0 + 4 * u + grp < nr) ? d : -INFINITY;
+          mb = fmaxf(mb, s[u]);
+        }
+      }
+      const float mbs = mb == -INFINITY ? 0.f : mb;      // a lane group without a real row yet: all weights 0
+      const float sc = __builtin_amdgcn_exp2f(m - mbs);   // m = -inf -> 0
+      acc *= sc;
+      l *= sc;
+#pragma unroll
+      for (int u = 0; u < kU / 2; ++u) {
+        const float p = __builtin_amdgcn_exp2f(s[u] - mbs);
+        acc += kr[u] * p;
+        l += p;
+      }
+      if (second) {
+#pragma unroll
+        for (int u = kU / 2; u < kU; ++u) {
+          const float p = __builtin_amdgcn_exp2f(s[u] - mbs);
+          acc += kr[u] * p;
+          l += p;
+        }
+      }
+      m = mb;
+    }
+    // merge the four group states
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+      f32x4 a2;
+      a2.x = __shfl_xor(acc.x, o, 64);
+      a2.y = __shfl_xor(acc.y, o, 64);
+      a2.z = __shfl_xor(acc.z, o, 64);
+      a2.w = __shfl_xor(acc.w, o, 64);
+      const float mn = fmaxf(m, m2);
+      const float s1 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+      const float s2 = m2 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+      acc = acc * s1 + a2 * s2;
+      l = l * s1 + l2 * s2;
+      m = mn;
+    }
+    // the S - nr zero rows: logit 0 each, value 0
+    const int nz = S - nr;
+    if (nz > 0) {
+      const float mn = fmaxf(m, 0.f);
+      const float s1 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+      acc *= s1;
+      l = l * s1 + (float)nz * __builtin_amdgcn_exp2f(-mn);
+    }
+    acc *= 1.f / l;
+    // f32x4-per-sub layout -> one element per lane
+    float pooled;
+    {
+      const int src = lane >> 2;
+      const float t0 = __shfl(acc.x, src, 64), t1 = __shfl(acc.y, src, 64);
+      const float t2 = __shfl(acc.z, src, 64), t3 = __shfl(acc.w, src, 64);
+      const int c = lane & 3;
+      pooled = c == 0 ? t0 : c == 1 ? t1 : c == 2 ? t2 : t3;
+    }
+    // ---- Wv, LN1, FFN, LN2 * mask -------------------------------------------------------------------------------
+    const float att = matvec64<64>(Wv, pooled, lane, vec[64 + lane]);
+    const float out1 = layer_norm64(x_last + att, vec[128 + lane], vec[192 + lane], P.eps1);
+    float f = vec[256 + lane];
+#pragma unroll
+    for (int hb = 0; hb < FH / 64; ++hb) {
+      const float h = relu_nan(matvec64<FH>(W1, out1, hb * 64 + lane, vec[448 + hb * 64 + lane]));
+      f = matvec64<64>(W2 + hb * 64 * 64, h, lane, f);
+    }
+    const float si = layer_norm64(out1 + f, vec[320 + lane], vec[384 + lane], P.eps2) * mask_last;
+    if (seq_info) seq_info[b * kD + lane] = si;
+    // ---- candidates: logits[b, j] = table_j[id_j] . seq_info ----------------------------------------------------
+    f32x4 sv;
+    sv.x = __shfl(si, sub * 4, 64);
+    sv.y = __shfl(si, sub * 4 + 1, 64);
+    sv.z = __shfl(si, sub * 4 + 2, 64);
+    sv.w = __shfl(si, sub * 4 + 3, 64);
+    for (int j0 = 0; j0 < n_cand; j0 += 64) {
+      const int j = j0 + lane;
+      int32_t idv = -1;
+      bool okv = false;
+      if (j < n_pos) {
+        idv = pos_ids[b * pos_stride + j];
+        okv = (uint32_t)idv < (uint32_t)pos_vocab;
+      } else if (j < n_cand) {
+        idv = neg_ids[b * neg_stride + (j - n_pos)];
+        okv = (uint32_t)idv < (uint32_t)neg_vocab;
+      }
+      if (!okv && j < n_cand && oob) *oob = 1;
+      idv = okv ? idv : -1;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int jb = j0 + half * 32;
+        if (jb >= n_cand) break;
+        // 8 load instructions = 32 candidates; the second four only when they hold a candidate (wave-uniform test);
+        // slots past the end read row 0 of the table and are not stored
+        f32x4 kr[kU];
+        int32_t idr[kU];
+        const bool second = jb + 2 * kU < n_cand;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) idr[u] = __shfl(idv, half * 32 + 4 * u + grp, 64);
+#pragma unroll
+        for (int u = 0; u < kU / 2; ++u) {
+          const float* t = (jb + 4 * u + grp < n_pos ? pos_table : neg_table) + sub * 4;
+          kr[u] = *reinterpret_cast<const f32x4*>(t + (int64_t)(idr[u] >= 0 ? idr[u] : 0) * kD);
+        }
+        if (second) {
+#pragma unroll
+          for (int u = kU / 2; u < kU; ++u) {
+            const float* t = (jb + 4 * u + grp < n_pos ? pos_table : neg_table) + sub * 4;
+            kr[u] = *reinterpret_cast<const f32x4*>(t + (int64_t)(idr[u] >= 0 ? idr[u] : 0) * kD);
+          }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < kU / 2; ++u) {
+          float d = kr[u].x * sv.x;
+          d = fmaf(kr[u].y, sv.y, d);
+          d = fmaf(kr[u].z, sv.z, d);
+          d = fmaf(kr[u].w, sv.w, d);
+          d = group16_sum(d);
+          d = idr[u] >= 0 ? d : 0.f;
+          mine = (sub & 7) == u ? d : mine;
+        }
+        if (second) {
+#pragma unroll
+          for (int u = kU / 2; u < kU; ++u) {
+            float d = kr[u].x * sv.x;
+            d = fmaf(kr[u].y, sv.y, d);
+            d = fmaf(kr[u].z, sv.z, d);
+            d = fmaf(kr[u].w, sv.w, d);
+            d = group16_sum(d);
+            d = idr[u] >= 0 ? d : 0.f;
+            mine = (sub & 7) == u ? d : mine;
+          }
+        }
+        const int jw = jb + 4 * sub + grp;       // lanes sub < 8 of group grp hold candidate jb + 4 sub + grp
+        if (sub < 8 && jw < n_cand) logits[b * logits_stride + jw] = mine;
+      }
+    }
+  }
+}
+
+template <int FH>
+size_t lds_bytes(int lst_cap) {
+  return (size_t)(64 * 64 + 64 * 65 + 60 + 64 * 64 + 2 * 64 * FH + 7 * 64 + FH) * 4 + (size_t)kWaves * lst_cap * 4;
+}
+
+}  // namespace
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
+                                       const int32_t* seq_ids, int64_t seq_ids_stride, int32_t S, int32_t pad_id,
+                                       const int32_t* mask_ids, int64_t mask_stride, const float* pos_table,
+                                       int32_t pos_vocab, const int32_t* pos_ids, int64_t pos_ids_stride, int32_t n_pos,
+                                       const float* neg_table, int32_t neg_vocab, const int32_t* neg_ids,
+                                       int64_t neg_ids_stride, int32_t n_neg, int64_t B, int32_t d, float* seq_info,
+                                       float* logits, int64_t logits_stride, int32_t* oob_flag, void* stream) {
+  REC_CHECK_ARG(blk && seq_table && seq_ids && mask_ids && logits, REC_EINVAL, "sasrec_last_row: NULL argument");
+  REC_CHECK_ARG(blk->wq && blk->bq && blk->wk && blk->wv && blk->bv && blk->ln1_gamma && blk->ln1_beta && blk->w1 &&
+                    blk->b1 && blk->w2 && blk->b2 && blk->ln2_gamma && blk->ln2_beta,
+                REC_EINVAL, "sasrec_last_row: NULL weight pointer in rec_sasrec_block");
+  REC_CHECK_ARG(d == 64, REC_ENOTIMPL, "sasrec_last_row: d_model = %d (this kernel: 64)", d);
+  REC_CHECK_ARG(blk->ffn_hidden == 64 || blk->ffn_hidden == 128, REC_ENOTIMPL,
+                "sasrec_last_row: ffn_hidden = %d (this kernel: 64 or 128)", blk->ffn_hidden);
+  REC_CHECK_ARG(S >= 1 && S <= 1024, REC_ESHAPE, "sasrec_last_row: S = %d outside [1, 1024]", S);
+  REC_CHECK_ARG(B >= 0 && n_pos >= 0 && n_neg >= 0 && seq_vocab > 0, REC_ESHAPE, "sasrec_last_row: negative size");
+  REC_CHECK_ARG(n_pos == 0 || (pos_table && pos_ids && pos_vocab > 0), REC_EINVAL, "sasrec_last_row: pos table/ids NULL");
+  REC_CHECK_ARG(n_neg == 0 || (neg_table && neg_ids && neg_vocab > 0), REC_EINVAL, "sasrec_last_row: neg table/ids NULL");
+  REC_CHECK_ARG(seq_ids_stride >= S && pos_ids_stride >= n_pos && neg_ids_stride >= n_neg &&
+                    logits_stride >= n_pos + n_neg,
+                REC_ESHAPE, "sasrec_last_row: a row stride is smaller than its row");
+  REC_CHECK_ARG(aligned16(seq_table) && (!pos_table || aligned16(pos_table)) && (!neg_table || aligned16(neg_table)) &&
+                    aligned16(blk->wq) && aligned16(blk->wv) && aligned16(blk->w1) && aligned16(blk->w2),
+                REC_EINVAL, "sasrec_last_row: tables and weight matrices must be 16-byte aligned");
+  if (B == 0) return REC_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  SasrecParams P{blk->wq, blk->bq, blk->wk, blk->wv, blk->bv, blk->ln1_gamma, blk->ln1_beta, blk->w1, blk->b1,
+                 blk->w2, blk->b2, blk->ln2_gamma, blk->ln2_beta, blk->ln1_eps, blk->ln2_eps, blk->ffn_hidden};
+  const int lst_cap = (S + 63) & ~63;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      set_error("sasrec_last_row: cannot query the device");
+      return REC_EHIP;
+    }
+    cus = prop.multiProcessorCount;
+  }
+  const int64_t wgs = (B + kWaves - 1) / kWaves;
+  const int grid = (int)(wgs < cus ? wgs : cus);
+  auto launch = [&](auto kern, size_t lds) -> int {
+    if (lds > 160 * 1024) {
+      set_error("sasrec_last_row: S = %d needs %zu bytes of LDS (> 160 KiB)", S, lds);
+      return REC_ENOTIMPL;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      set_error("sasrec_last_row: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return REC_EHIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds, st, P, seq_table, seq_vocab, seq_ids, seq_ids_stride,
+                       (int)S, pad_id, mask_ids, mask_stride, pos_table, pos_vocab, pos_ids, pos_ids_stride, (int)n_pos,
+                       neg_table, neg_vocab, neg_ids, neg_ids_stride, (int)n_neg, B, seq_info, logits, logits_stride,
+                       reinterpret_cast<int*>(oob_flag), lst_cap);
+    return REC_OK;
+  };
+  int rc = blk->ffn_hidden == 128 ? launch(sasrec_last_row_kernel<128>, lds_bytes<128>(lst_cap))
+                                  : launch(sasrec_last_row_kernel<64>, lds_bytes<64>(lst_cap));
+  if (rc != REC_OK) return rc;
+  REC_CHECK_LAUNCH("sasrec_last_row");
+  return REC_OK;
+}

@@ -71,6 +71,17 @@ class SASRec(Model):
     def call(self, inputs, **kwargs):
         seq_inputs, pos_inputs, neg_inputs = [to_device_ids(t, self.device) for t in inputs]
         B, S = seq_inputs.shape
+        fused = self._fused_block(S, seq_inputs, pos_inputs, neg_inputs)
+        if fused and self._sharded is None:
+            # everything from the ids to the logits in ONE launch: pad id 0 -> zero row inside the kernel (:81-82)
+            tb = self.user_embed_layers
+            logits, seq_info = ops.sasrec_last_row(
+                fused, self.encoder_layer[0].layernorm1.epsilon, self.encoder_layer[0].layernorm2.epsilon,
+                tb['embed_seq_item'].table, seq_inputs, 0, seq_inputs[:, -1], seq_inputs.stride(0),
+                tb['embed_pos_item'].table, pos_inputs, tb['embed_neg_item'].table, neg_inputs)
+            self.embed = seq_info[:, None, :]
+            self._logits = logits
+            return logits
         mask = (seq_inputs != 0).to(torch.float32)                                        # :72 (B,S)
         if self._sharded is None:
             # :75 + :81-82 in one pass: `seq_embed * mask` zeroes exactly the rows whose id is 0, so pad ids
@@ -90,6 +101,13 @@ class SASRec(Model):
             pos_inputs = uidx[B * S: B * S + B].view(B, 1)
             neg_inputs = uidx[B * S + B:].view(B, n_neg)
             seq_table = pos_table = neg_table = rows
+            if fused:   # the same single launch, reading the returned rows through the per-lookup index
+                logits, seq_info = ops.sasrec_last_row(
+                    fused, self.encoder_layer[0].layernorm1.epsilon, self.encoder_layer[0].layernorm2.epsilon,
+                    rows, seq_m, -1, seq_inputs[:, -1], seq_inputs.stride(0), rows, pos_inputs, rows, neg_inputs)
+                self.embed = seq_info[:, None, :]
+                self._logits = logits
+                return logits
 
         def embed(table, ids):                                                            # Embedding.call on `table`
             return ops.gather_concat(ops.TableGroup([table]), ids.reshape(-1, 1).contiguous()).view(*ids.shape, -1)
@@ -121,6 +139,30 @@ class SASRec(Model):
         ops.gather_dot_scores(seq_info, neg_table, neg_inputs.contiguous(), out=logits[:, 1:])   # :79,:91
         self._logits = logits          # the add_loss value (:93-95) is computed on demand: `model.losses`
         return logits                                                                     # :96
+
+    def _fused_block(self, S, seq_inputs, pos_inputs, neg_inputs):
+        """The 13 weight tensors of the single encoder block when the one-launch kernel serves this configuration
+        (one block, one head, last row only, d_model 64, ffn 64/128, int32 ids), else None.  REC_SASREC_IMPL=layers
+        keeps the layer-by-layer path."""
+        import os
+        if len(self.encoder_layer) != 1 or not self.last_row_only or os.environ.get('REC_SASREC_IMPL') == 'layers':
+            return None
+        enc = self.encoder_layer[0]
+        if enc.mha.num_heads != 1 or any(t.dtype != torch.int32 for t in (seq_inputs, pos_inputs, neg_inputs)):
+            return None
+        ffn_hidden = enc.ffn.conv1.units
+        if not ops.sasrec_last_row_supported(self.d_model, ffn_hidden, S):
+            return None
+        d = self.d_model
+        for layer, n_in in ((enc.mha.wq, d), (enc.mha.wk, d), (enc.mha.wv, d), (enc.ffn.conv1, d), (enc.ffn.conv2, ffn_hidden),
+                            (enc.layernorm1, d), (enc.layernorm2, d)):
+            if not layer.built:
+                layer.build(n_in)
+        w = lambda l, k: l._w[k]  # noqa: E731
+        return (w(enc.mha.wq, 'kernel'), w(enc.mha.wq, 'bias'), w(enc.mha.wk, 'kernel'), w(enc.mha.wv, 'kernel'),
+                w(enc.mha.wv, 'bias'), w(enc.layernorm1, 'gamma'), w(enc.layernorm1, 'beta'), w(enc.ffn.conv1, 'kernel'),
+                w(enc.ffn.conv1, 'bias'), w(enc.ffn.conv2, 'kernel'), w(enc.ffn.conv2, 'bias'), w(enc.layernorm2, 'gamma'),
+                w(enc.layernorm2, 'beta'))
 
     @property
     def losses(self):

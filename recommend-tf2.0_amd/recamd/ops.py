@@ -426,6 +426,47 @@ def gather_dot_scores(seq_info: torch.Tensor, table: torch.Tensor, ids: torch.Te
     return out
 
 
+def sasrec_last_row_supported(d_model: int, ffn_hidden: int, S: int) -> bool:
+    """Shapes served by the one-launch SASRec kernel (rec_sasrec_last_row_f32)."""
+    return d_model == 64 and ffn_hidden in (64, 128) and 1 <= S <= 512
+
+
+def sasrec_last_row(weights, eps1, eps2, seq_table, seq_ids, pad_id, mask_ids, mask_stride, pos_table, pos_ids, neg_table,
+                    neg_ids, oob_flag=None):
+    """SASRec with one encoder block / one head, last position only, in ONE launch (src/match/sasrec/model.py:72-96).
+    weights = (wq, bq, wk, wv, bv, ln1_gamma, ln1_beta, w1, b1, w2, b2, ln2_gamma, ln2_beta), Keras layouts.
+    seq_ids (B, S) int32: id == pad_id or out of range -> zero row.  mask_ids: an int32 tensor VIEW whose element
+    [b * mask_stride] != 0 is sample b's query / output mask.  Returns (logits (B, n_pos + n_neg), seq_info (B, d))."""
+    ws = [_chk(w, "weight").contiguous() for w in weights]
+    if len(ws) != 13:
+        raise ValueError("sasrec_last_row: 13 weight tensors expected")
+    for tb in (seq_table, pos_table, neg_table):
+        if not _chk(tb, "table").is_contiguous():
+            raise ValueError("sasrec_last_row: tables must be contiguous")
+    _rows2d(_chk(seq_ids, "seq_ids", torch.int32), "seq_ids")
+    _rows2d(_chk(pos_ids, "pos_ids", torch.int32), "pos_ids")
+    _rows2d(_chk(neg_ids, "neg_ids", torch.int32), "neg_ids")
+    _chk(mask_ids, "mask_ids", torch.int32)
+    B, S = seq_ids.shape
+    d = seq_table.shape[1]
+    fh = ws[7].shape[1]
+    if pos_ids.shape[0] != B or neg_ids.shape[0] != B or pos_table.shape[1] != d or neg_table.shape[1] != d:
+        raise ValueError("sasrec_last_row: inconsistent shapes")
+    if tuple(ws[0].shape) != (d, d) or tuple(ws[2].shape) != (d, d) or tuple(ws[3].shape) != (d, d) or \
+            tuple(ws[7].shape) != (d, fh) or tuple(ws[9].shape) != (fh, d):
+        raise ValueError("sasrec_last_row: weight shapes do not match d_model / ffn_hidden")
+    n_pos, n_neg = pos_ids.shape[1], neg_ids.shape[1]
+    logits = torch.empty((B, n_pos + n_neg), dtype=torch.float32, device=seq_ids.device)
+    seq_info = torch.empty((B, d), dtype=torch.float32, device=seq_ids.device)
+    C.sasrec_last_row_f32([w.data_ptr() for w in ws], float(eps1), float(eps2), int(fh), seq_table.data_ptr(),
+                          int(seq_table.shape[0]), seq_ids.data_ptr(), seq_ids.stride(0), S, int(pad_id), mask_ids.data_ptr(),
+                          int(mask_stride), pos_table.data_ptr(), int(pos_table.shape[0]), pos_ids.data_ptr(),
+                          pos_ids.stride(0), n_pos, neg_table.data_ptr(), int(neg_table.shape[0]), neg_ids.data_ptr(),
+                          neg_ids.stride(0), n_neg, B, d, seq_info.data_ptr(), logits.data_ptr(), logits.stride(0),
+                          _ptr(oob_flag), _stream())
+    return logits, seq_info
+
+
 def shard_bucket(ids_flat: torch.Tensor, G: int):
     """Stable bucketing of a flat int32 id list by owner = id % G.
     Returns (counts[G] int32, perm[n] int32, send_local[n] int32)."""
