@@ -248,8 +248,8 @@ def wl_sasrec(torch, dev, a, rank, world):
 
     need = B * ((S + 1 + n) * 4 + (1 + n) * d * 4 + (1 + n) * 4) + (real / NB) * d * 4
     return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "kernel": "SASRec forward, exact last-row form (rec_gather_mha_fewq_f32 + FFN/LN on one row + "
-                      "rec_gather_dot_scores_f32): item rows read once", "pmc_key": None,
+            "kernel": "sasrec_last_row_kernel (rec_sasrec_last_row_f32): the whole forward in one launch, exact last-row "
+                      "form, item rows of real positions read once", "pmc_key": None,
             "workload": "SASRec seq 200 dim 64, 10M-item tables, 1 block, 100 negatives, global batch 8192 "
                         "(BASELINE configs[4])" + (", tables row-sharded over the ranks (RCCL all-to-all)"
                                                    if a.placement == "rowshard" else ""),

@@ -244,8 +244,9 @@ int rec_mha_rowmask_f32(const float* q, const float* k, const float* v, const fl
  * of sample b is mask_ids[b * mask_stride] != 0 (pass seq_ids + S - 1 with stride seq_ids_stride for the reference's
  * `seq != 0`).  Candidates: n_pos ids from pos_table then n_neg ids from neg_table (the reference's three DIFFERENT
  * tables); logits[b, j] = candidate_j . seq_info[b], j < n_pos + n_neg.  seq_info (B, d) may be NULL.
- * This kernel: d = 64, ffn_hidden in {64, 128}, S <= ~600 (LDS); other shapes return REC_ENOTIMPL and the caller
- * composes rec_gather_mha_fewq_f32 / rec_dense_f32 / rec_layernorm_residual_f32 / rec_gather_dot_scores_f32. */
+ * This kernel: d = 64, ffn_hidden in {64, 128}, and S / candidate counts whose id buffers fit the LDS next to the
+ * weights (S <= 256 with <= 128 candidates at ffn 128; rec_sasrec_last_row_supported answers 1 / 0); other shapes
+ * return REC_ENOTIMPL and the caller composes rec_gather_mha_fewq_f32 / rec_dense_f32 / rec_layernorm_residual_f32 / rec_gather_dot_scores_f32. */
 typedef struct rec_sasrec_block {
   const float *wq, *bq, *wk, *wv, *bv;
   const float *ln1_gamma, *ln1_beta;
@@ -254,6 +255,7 @@ typedef struct rec_sasrec_block {
   float ln1_eps, ln2_eps;
   int32_t ffn_hidden;
 } rec_sasrec_block;
+int rec_sasrec_last_row_supported(int32_t d, int32_t ffn_hidden, int32_t S, int32_t n_cand);
 int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
                             const int32_t* seq_ids, int64_t seq_ids_stride, int32_t S, int32_t pad_id,
                             const int32_t* mask_ids, int64_t mask_stride, const float* pos_table, int32_t pos_vocab,

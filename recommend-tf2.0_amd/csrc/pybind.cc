@@ -565,6 +565,9 @@ PYBIND11_MODULE(_C, m) {
                                 P<float>(out), P<void>(stream)),
           "rec_mha_ctr_stack_f32");
   });
+  m.def("sasrec_last_row_supported", [](int d, int ffn_hidden, int S, int n_cand) {
+    return rec_sasrec_last_row_supported(d, ffn_hidden, S, n_cand) != 0;
+  });
   m.def("sasrec_last_row_f32", [](const std::vector<ptr_t>& w, float eps1, float eps2, int ffn_hidden, ptr_t seq_table,
                                   int seq_vocab, ptr_t seq_ids, int64_t seq_stride, int S, int pad_id, ptr_t mask_ids,
                                   int64_t mask_stride, ptr_t pos_table, int pos_vocab, ptr_t pos_ids, int64_t pos_stride,

@@ -22,7 +22,14 @@
 // staged once per workgroup into LDS in their Keras (in, out) layout — lane o reads W[i][o], conflict-free — Wk
 // transposed with a padded stride; a workgroup is 16 waves (one per CU: the weights take most of the LDS) that
 // walk the samples persistently and never synchronise again.  Row fetches use 16 lanes per 256-B row (16 B each),
-// 4 rows per wave instruction, 8 instructions (8 KiB) in flight per wave.
+// 4 rows per wave instruction, two landing buffers of kU instructions each per wave.
+//
+// Measured (MI355X, config 5): 234 us unfused -> 100.6 us (first version: one landing buffer of 8 loads, ids fetched
+// when needed) -> 91.6 us (ids by LDS-DMA one sample ahead, two landing buffers of 4 loads, fetches issued before the
+// matvec chains) = 4.8 TB/s of required bytes.  8 loads per buffer spill (10 VGPRs) and run at 112 us: a spilled
+// landing register is a wait for its load.  With every sample at the mean length: 86 us, so the static sample ->
+// wave assignment costs 6 %; the rest is bytes in flight: 16 waves x 8 KiB per CU is all the VGPR file gives at 128
+// registers per wave, and the LDS that could land more is full of weights.
 #include "common.h"
 
 namespace rec {
@@ -31,7 +38,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kD = 64;       // d_model
 constexpr int kWaves = 16;   // per workgroup
-constexpr int kU = 8;        // row-load instructions in flight per wave (4 rows each)
+#ifndef REC_SASREC_KU
+#define REC_SASREC_KU 4
+#endif
+constexpr int kU = REC_SASREC_KU;   // row-load instructions per landing buffer (4 rows each); two buffers per wave
 
 struct SasrecParams {
   const float *wq, *bq, *wk, *wv, *bv, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
@@ -43,19 +53,37 @@ __device__ __forceinline__ float bcast(float v, int src_lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+// LDS-DMA, 4 B per active lane: LDS[lds + 4 * lane] <- *g.  No VGPR destination: the wave does not hold (or spill,
+// which would mean waiting for) what it prefetches.  The compiler does not see this load in its vmcnt bookkeeping; its
+// own waits then only become stricter (loads retire in issue order), never too weak.
+__device__ __forceinline__ void glds4(const void* g, uint32_t lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds)
+      : "memory");
+}
+
 // y[lane] = sum_i x_i W[i][col], x one element per lane, W in LDS with row stride `ld`; four partial sums
 // (the column index is laundered through an empty asm: the weights do not depend on the sample, and without it the
-// compiler hoists all 28 672 / 64 weight reads out of the persistent loop and spills them)
+// compiler hoists all 28 672 / 64 weight reads out of the persistent loop and spills them).
 template <int LD>
 __device__ __forceinline__ float matvec64(const float* __restrict__ W, float x, int col, float init) {
-  asm volatile("" : "+v"(col));
   float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  // a real loop over blocks of 16 rows (not unrolled): 16 weight reads in registers at a time — the row landing buffers
+  // of the caller hold 64 of the wave's 128 VGPRs while this runs
+#pragma unroll 1
+  for (int i0 = 0; i0 < 64; i0 += 16) {
+    asm volatile("" : "+v"(col));
+    const float* Wb = W + i0 * LD + col;
 #pragma unroll
-  for (int i = 0; i < 64; i += 4) {
-    a0 = fmaf(bcast(x, i), W[(i)*LD + col], a0);
-    a1 = fmaf(bcast(x, i + 1), W[(i + 1) * LD + col], a1);
-    a2 = fmaf(bcast(x, i + 2), W[(i + 2) * LD + col], a2);
-    a3 = fmaf(bcast(x, i + 3), W[(i + 3) * LD + col], a3);
+    for (int i = 0; i < 16; i += 4) {
+      a0 = fmaf(bcast(x, i0 + i), Wb[(i)*LD], a0);
+      a1 = fmaf(bcast(x, i0 + i + 1), Wb[(i + 1) * LD], a1);
+      a2 = fmaf(bcast(x, i0 + i + 2), Wb[(i + 2) * LD], a2);
+      a3 = fmaf(bcast(x, i0 + i + 3), Wb[(i + 3) * LD], a3);
+    }
   }
   return (a0 + a1) + (a2 + a3);
 }
@@ -80,7 +108,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     const float* __restrict__ pos_table, int32_t pos_vocab, const int32_t* __restrict__ pos_ids, int64_t pos_stride,
     int n_pos, const float* __restrict__ neg_table, int32_t neg_vocab, const int32_t* __restrict__ neg_ids,
     int64_t neg_stride, int n_neg, int64_t B, float* __restrict__ seq_info, float* __restrict__ logits,
-    int64_t logits_stride, int* __restrict__ oob, int lst_cap) {
+    int64_t logits_stride, int* __restrict__ oob, int lst_cap, int cand_cap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int LDK = 65;                       // padded row stride of Wk^T
   float* const Wq = lds;                        // [64][64]   (in, out)
@@ -89,7 +117,9 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
   float* const W1 = Wv + 64 * 64;               // [64][FH]
   float* const W2 = W1 + 64 * FH;               // [FH][64]
   float* const vec = W2 + FH * 64;              // bq bv g1 be1 b2 g2 be2 (64 each), b1 (FH)
-  int32_t* const lst_all = reinterpret_cast<int32_t*>(vec + 7 * 64 + FH);
+  // per wave: two sequence-id buffers (the list of real rows is compacted in place in the one being consumed, the other
+  // receives the next sample's ids), the candidate ids, two mask words
+  int32_t* const wave_lds = reinterpret_cast<int32_t*>(vec + 7 * 64 + FH) + (threadIdx.x >> 6) * (2 * lst_cap + cand_cap + 2);
   const int tid = threadIdx.x;
   for (int e = tid * 4; e < 64 * 64; e += kWaves * 64 * 4) {
     *reinterpret_cast<f32x4*>(Wq + e) = *reinterpret_cast<const f32x4*>(P.wq + e);
@@ -112,19 +142,53 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
   if (tid < FH) vec[448 + tid] = P.b1[tid];
   __syncthreads();
 
-  const int lane = tid & 63, wave = tid >> 6;
-  const int sub = lane & 15, grp = lane >> 4;
-  int32_t* const lst = lst_all + wave * lst_cap;
+  const int lane_c = tid & 63, wave = tid >> 6;
   const float scale_log2e = 1.4426950408889634f * 0.125f;   // log2(e) / sqrt(64)
   const int n_cand = n_pos + n_neg;
+  int32_t* const cbuf = wave_lds + 2 * lst_cap;
+  int32_t* const msk = cbuf + cand_cap;
+  // LDS byte address of this wave's area (wave-uniform; readfirstlane tells the compiler so)
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)wave_lds);
 
-  for (int64_t b = (int64_t)blockIdx.x * kWaves + wave; b < B; b += (int64_t)gridDim.x * kWaves) {
-    // ---- compacted list of the slots that hold a real row; everything else is a zero row ----------------------
-    const int32_t* ids_b = seq_ids + b * seq_stride;
+  // ---- per-sample pipeline ---------------------------------------------------------------------------------------
+  // A wave's samples are a serial chain of memory round trips (ids -> rows -> ... -> candidate rows); with 16 waves per
+  // CU that chain, not the bandwidth, set the first version's time (100 us).  So every fetch is issued as early as its
+  // address is known: the NEXT sample's ids and this sample's candidate ids by LDS-DMA at the top (no registers: a
+  // prefetched value the compiler has to spill is a value it waits for); the last row and the first two row batches
+  // before the Wq / Wk matvecs; row batch i + 2 as soon as batch i has been reduced (two landing buffers in
+  // registers); the first two candidate batches before the Wv / LN / FFN chain (candidate rows do not depend on it).
+  const int64_t bstep = (int64_t)gridDim.x * kWaves;
+  int64_t b = (int64_t)blockIdx.x * kWaves + wave;
+  auto prefetch_seq_ids = [&](int64_t bb, int which) {
+    for (int c = 0; c * 64 < S; ++c)
+      if (c * 64 + lane_c < S) glds4(seq_ids + bb * seq_stride + c * 64 + lane_c, lds0 + (uint32_t)(which * lst_cap + c * 64) * 4u);
+    if (lane_c == 0) glds4(mask_ids + bb * mask_stride, lds0 + (uint32_t)(2 * lst_cap + cand_cap + which) * 4u);
+  };
+  if (b < B) prefetch_seq_ids(b, 0);
+  int cur = 0;
+  for (; b < B; b += bstep, cur ^= 1) {
+    // everything lane-dependent below derives from a laundered lane index: otherwise the compiler hoists dozens of
+    // per-lane invariants (bias reads, table-select pointers of every unrolled slot) out of this loop and spills them
+    int ln = lane_c;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ln) : : "memory");     // this sample's ids have landed in LDS
+    const int lane = ln, sub = ln & 15, grp = ln >> 4;
+    const float* tb = seq_table + sub * 4;
+    int32_t* const lst = wave_lds + cur * lst_cap;
+    // ---- DMA: this sample's candidate ids, the next sample's sequence ids + mask ------------------------------
+    for (int c = 0; c * 64 < n_cand; ++c) {
+      const int j = c * 64 + lane;
+      if (j < n_cand)
+        glds4(j < n_pos ? pos_ids + b * pos_stride + j : neg_ids + b * neg_stride + (j - n_pos),
+              lds0 + (uint32_t)(2 * lst_cap + c * 64) * 4u);
+    }
+    if (b + bstep < B) prefetch_seq_ids(b + bstep, cur ^ 1);
+    // ---- list of the slots that hold a real row, compacted in place; everything else is a zero row --------------
+    const int32_t id_last = lst[S - 1];
+    const float mask_last = msk[cur] != 0 ? 1.f : 0.f;
     int nr = 0;
-    for (int j0 = 0; j0 < S; j0 += 64) {
-      const int j = j0 + lane;
-      const int32_t id = j < S ? ids_b[j] : pad_id;
+    for (int c = 0; c * 64 < S; ++c) {
+      const int j = c * 64 + lane;
+      const int32_t id = j < S ? lst[j] : pad_id;
       const bool is_pad = id == pad_id || j >= S;
       const bool ok = !is_pad && (uint32_t)id < (uint32_t)seq_vocab;
       if (!ok && !is_pad && oob) *oob = 1;
@@ -132,11 +196,24 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
       if (ok) lst[nr + __popcll(bal & ((1ull << lane) - 1ull))] = id;
       nr += __popcll(bal);
     }
-    const int32_t id_last = ids_b[S - 1];
+    if (nr == 0 && lane == 0) lst[0] = 0;          // the clamped fetches below need one valid row id
+    const int nr1 = nr > 0 ? nr - 1 : 0;
     const bool last_ok = id_last != pad_id && (uint32_t)id_last < (uint32_t)seq_vocab;
-    const float mask_last = mask_ids[b * mask_stride] != 0 ? 1.f : 0.f;
-    // ---- last position: x -> q = x Wq + bq -> q_back = Wk q ---------------------------------------------------
+    // ---- issue: last row, row batches 0 and 1 ---------------------------------------------------------------------
     float x_last = seq_table[(int64_t)(last_ok ? id_last : 0) * kD + lane];
+    f32x4 ka[kU], kb[kU];
+    // every issue is unconditional (rows past the end re-read the last real row: a cache hit): a conditional one makes
+    // the landing buffers phi values and the register allocator answers with copies and spills
+    auto issue_rows = [&](f32x4(&kr)[kU], int r0) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int r = r0 + 4 * u + grp;
+        kr[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr1] * kD);
+      }
+    };
+    issue_rows(ka, 0);
+    issue_rows(kb, 4 * kU);
+    // ---- last position: x -> q = x Wq + bq -> q_back = Wk q ---------------------------------------------------
     x_last = last_ok ? x_last : 0.f;
     const float q = matvec64<64>(Wq, x_last, lane, vec[lane]);
     const float q_back = matvec64<LDK>(WkT, q, lane, 0.f);
@@ -149,64 +226,56 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     const bool masked = mask_last == 0.f;      // masked query row: all logits equal -> uniform over all S keys
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* tb = seq_table + sub * 4;
-    for (int r0 = 0; r0 < nr; r0 += 4 * kU) {
-      // two halves of kU/2 load instructions; the second one only when it holds a real row (wave-uniform test).  Rows
-      // past the end re-read the last real row (a cache hit) and enter the softmax with the logit -inf (weight 0).
-      f32x4 kr[kU];
+    // rows past the end enter the softmax with the logit -inf (weight 0)
+    auto reduce_rows = [&](f32x4(&kr)[kU], int r0) {
       float s[kU];
-      const bool second = r0 + 2 * kU < nr;
-#pragma unroll
-      for (int u = 0; u < kU / 2; ++u) {
-        const int r = r0 + 4 * u + grp;
-        kr[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr - 1] * kD);
-      }
-      if (second) {
-#pragma unroll
-        for (int u = kU / 2; u < kU; ++u) {
-          const int r = r0 + 4 * u + grp;
-          kr[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr - 1] * kD);
-        }
-      }
       float mb = m;
 #pragma unroll
-      for (int u = 0; u < kU / 2; ++u) {
+      for (int u = 0; u < kU; ++u) {
         const f32x4 pr = kr[u] * qv;
         float d = group16_sum((pr.x + pr.y) + (pr.z + pr.w));
         d = masked ? 0.f : d * scale_log2e;
         s[u] = (r0 + 4 * u + grp < nr) ? d : -INFINITY;
         mb = fmaxf(mb, s[u]);
       }
-      if (second) {
-#pragma unroll
-        for (int u = kU / 2; u < kU; ++u) {
-          const f32x4 pr = kr[u] * qv;
-          float d = group16_sum((pr.x + pr.y) + (pr.z + pr.w));
-          d = masked ? 0.f : d * scale_log2e;
-          s[u] = (r0 + 4 * u + grp < nr) ? d : -INFINITY;
-          mb = fmaxf(mb, s[u]);
-        }
-      }
       const float mbs = mb == -INFINITY ? 0.f : mb;      // a lane group without a real row yet: all weights 0
       const float sc = __builtin_amdgcn_exp2f(m - mbs);   // m = -inf -> 0
       acc *= sc;
       l *= sc;
 #pragma unroll
-      for (int u = 0; u < kU / 2; ++u) {
+      for (int u = 0; u < kU; ++u) {
         const float p = __builtin_amdgcn_exp2f(s[u] - mbs);
         acc += kr[u] * p;
         l += p;
       }
-      if (second) {
-#pragma unroll
-        for (int u = kU / 2; u < kU; ++u) {
-          const float p = __builtin_amdgcn_exp2f(s[u] - mbs);
-          acc += kr[u] * p;
-          l += p;
-        }
-      }
       m = mb;
+    };
+    for (int r0 = 0; r0 < nr; r0 += 8 * kU) {
+      reduce_rows(ka, r0);
+      issue_rows(ka, r0 + 8 * kU);
+      if (r0 + 4 * kU < nr) reduce_rows(kb, r0 + 4 * kU);
+      issue_rows(kb, r0 + 12 * kU);
     }
+    // ---- candidate batches 0 and 1 leave now; they land while the Wv / LN / FFN chain runs -------------------
+    const float* pos_t = n_pos > 0 ? pos_table : neg_table;     // slots past the end read row 0 of an existing table
+    const float* neg_t = n_neg > 0 ? neg_table : pos_table;
+    const int nc1 = n_cand - 1;
+    auto cand_id = [&](int j) -> int32_t {     // id of candidate j, -1 when out of range or past the end
+      const int32_t id = cbuf[j < n_cand ? j : nc1];
+      const bool ok = j < n_cand && (uint32_t)id < (uint32_t)(j < n_pos ? pos_vocab : neg_vocab);
+      return ok ? id : -1;
+    };
+    auto issue_cand = [&](f32x4(&kr)[kU], int jb) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int j = jb + 4 * u + grp;
+        const int32_t id = cand_id(j);
+        const float* tp = (j < n_pos ? pos_t : neg_t) + sub * 4;
+        kr[u] = *reinterpret_cast<const f32x4*>(tp + (int64_t)(id >= 0 ? id : 0) * kD);
+      }
+    };
+    issue_cand(ka, 0);
+    issue_cand(kb, 4 * kU);
     // merge the four group states
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
@@ -258,81 +327,51 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     sv.y = __shfl(si, sub * 4 + 1, 64);
     sv.z = __shfl(si, sub * 4 + 2, 64);
     sv.w = __shfl(si, sub * 4 + 3, 64);
-    for (int j0 = 0; j0 < n_cand; j0 += 64) {
-      const int j = j0 + lane;
-      int32_t idv = -1;
-      bool okv = false;
-      if (j < n_pos) {
-        idv = pos_ids[b * pos_stride + j];
-        okv = (uint32_t)idv < (uint32_t)pos_vocab;
-      } else if (j < n_cand) {
-        idv = neg_ids[b * neg_stride + (j - n_pos)];
-        okv = (uint32_t)idv < (uint32_t)neg_vocab;
+    auto reduce_cand = [&](f32x4(&kr)[kU], int jb) {
+      float mine = 0.f;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        float d = kr[u].x * sv.x;
+        d = fmaf(kr[u].y, sv.y, d);
+        d = fmaf(kr[u].z, sv.z, d);
+        d = fmaf(kr[u].w, sv.w, d);
+        d = group16_sum(d);
+        mine = sub == u ? d : mine;
       }
-      if (!okv && j < n_cand && oob) *oob = 1;
-      idv = okv ? idv : -1;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int jb = j0 + half * 32;
-        if (jb >= n_cand) break;
-        // 8 load instructions = 32 candidates; the second four only when they hold a candidate (wave-uniform test);
-        // slots past the end read row 0 of the table and are not stored
-        f32x4 kr[kU];
-        int32_t idr[kU];
-        const bool second = jb + 2 * kU < n_cand;
-#pragma unroll
-        for (int u = 0; u < kU; ++u) idr[u] = __shfl(idv, half * 32 + 4 * u + grp, 64);
-#pragma unroll
-        for (int u = 0; u < kU / 2; ++u) {
-          const float* t = (jb + 4 * u + grp < n_pos ? pos_table : neg_table) + sub * 4;
-          kr[u] = *reinterpret_cast<const f32x4*>(t + (int64_t)(idr[u] >= 0 ? idr[u] : 0) * kD);
-        }
-        if (second) {
-#pragma unroll
-          for (int u = kU / 2; u < kU; ++u) {
-            const float* t = (jb + 4 * u + grp < n_pos ? pos_table : neg_table) + sub * 4;
-            kr[u] = *reinterpret_cast<const f32x4*>(t + (int64_t)(idr[u] >= 0 ? idr[u] : 0) * kD);
-          }
-        }
-        float mine = 0.f;
-#pragma unroll
-        for (int u = 0; u < kU / 2; ++u) {
-          float d = kr[u].x * sv.x;
-          d = fmaf(kr[u].y, sv.y, d);
-          d = fmaf(kr[u].z, sv.z, d);
-          d = fmaf(kr[u].w, sv.w, d);
-          d = group16_sum(d);
-          d = idr[u] >= 0 ? d : 0.f;
-          mine = (sub & 7) == u ? d : mine;
-        }
-        if (second) {
-#pragma unroll
-          for (int u = kU / 2; u < kU; ++u) {
-            float d = kr[u].x * sv.x;
-            d = fmaf(kr[u].y, sv.y, d);
-            d = fmaf(kr[u].z, sv.z, d);
-            d = fmaf(kr[u].w, sv.w, d);
-            d = group16_sum(d);
-            d = idr[u] >= 0 ? d : 0.f;
-            mine = (sub & 7) == u ? d : mine;
-          }
-        }
-        const int jw = jb + 4 * sub + grp;       // lanes sub < 8 of group grp hold candidate jb + 4 sub + grp
-        if (sub < 8 && jw < n_cand) logits[b * logits_stride + jw] = mine;
+      const int jw = jb + 4 * sub + grp;       // lanes sub < kU of group grp hold candidate jb + 4 sub + grp
+      if (sub < kU && jw < n_cand) {
+        const int32_t id = cbuf[jw];
+        const bool ok = (uint32_t)id < (uint32_t)(jw < n_pos ? pos_vocab : neg_vocab);
+        if (!ok && oob) *oob = 1;
+        logits[b * logits_stride + jw] = ok ? mine : 0.f;      // out-of-range candidate: zero row
       }
+    };
+    for (int jb = 0; jb < n_cand; jb += 8 * kU) {
+      reduce_cand(ka, jb);
+      issue_cand(ka, jb + 8 * kU);
+      if (jb + 4 * kU < n_cand) reduce_cand(kb, jb + 4 * kU);
+      issue_cand(kb, jb + 12 * kU);
     }
   }
 }
 
 template <int FH>
-size_t lds_bytes(int lst_cap) {
-  return (size_t)(64 * 64 + 64 * 65 + 60 + 64 * 64 + 2 * 64 * FH + 7 * 64 + FH) * 4 + (size_t)kWaves * lst_cap * 4;
+size_t lds_bytes(int lst_cap, int cand_cap) {
+  return (size_t)(64 * 64 + 64 * 65 + 60 + 64 * 64 + 2 * 64 * FH + 7 * 64 + FH) * 4 +
+         (size_t)kWaves * (2 * lst_cap + cand_cap + 2) * 4;
 }
 
 }  // namespace
 }  // namespace rec
 
 using namespace rec;
+
+extern "C" int rec_sasrec_last_row_supported(int32_t d, int32_t ffn_hidden, int32_t S, int32_t n_cand) {
+  if (d != 64 || (ffn_hidden != 64 && ffn_hidden != 128) || S < 1 || n_cand < 1) return 0;
+  const int lst_cap = (S + 63) & ~63, cand_cap = (n_cand + 63) & ~63;
+  const size_t lds = ffn_hidden == 128 ? lds_bytes<128>(lst_cap, cand_cap) : lds_bytes<64>(lst_cap, cand_cap);
+  return lds <= 160 * 1024 ? 1 : 0;
+}
 
 extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
                                        const int32_t* seq_ids, int64_t seq_ids_stride, int32_t S, int32_t pad_id,
@@ -348,8 +387,9 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
   REC_CHECK_ARG(d == 64, REC_ENOTIMPL, "sasrec_last_row: d_model = %d (this kernel: 64)", d);
   REC_CHECK_ARG(blk->ffn_hidden == 64 || blk->ffn_hidden == 128, REC_ENOTIMPL,
                 "sasrec_last_row: ffn_hidden = %d (this kernel: 64 or 128)", blk->ffn_hidden);
-  REC_CHECK_ARG(S >= 1 && S <= 1024, REC_ESHAPE, "sasrec_last_row: S = %d outside [1, 1024]", S);
-  REC_CHECK_ARG(B >= 0 && n_pos >= 0 && n_neg >= 0 && seq_vocab > 0, REC_ESHAPE, "sasrec_last_row: negative size");
+  REC_CHECK_ARG(S >= 1, REC_ESHAPE, "sasrec_last_row: S = %d", S);
+  REC_CHECK_ARG(B >= 0 && n_pos >= 0 && n_neg >= 0 && n_pos + n_neg >= 1 && seq_vocab > 0, REC_ESHAPE,
+                "sasrec_last_row: negative size or no candidate");
   REC_CHECK_ARG(n_pos == 0 || (pos_table && pos_ids && pos_vocab > 0), REC_EINVAL, "sasrec_last_row: pos table/ids NULL");
   REC_CHECK_ARG(n_neg == 0 || (neg_table && neg_ids && neg_vocab > 0), REC_EINVAL, "sasrec_last_row: neg table/ids NULL");
   REC_CHECK_ARG(seq_ids_stride >= S && pos_ids_stride >= n_pos && neg_ids_stride >= n_neg &&
@@ -363,6 +403,7 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
   SasrecParams P{blk->wq, blk->bq, blk->wk, blk->wv, blk->bv, blk->ln1_gamma, blk->ln1_beta, blk->w1, blk->b1,
                  blk->w2, blk->b2, blk->ln2_gamma, blk->ln2_beta, blk->ln1_eps, blk->ln2_eps, blk->ffn_hidden};
   const int lst_cap = (S + 63) & ~63;
+  const int cand_cap = (n_pos + n_neg + 63) & ~63;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -377,7 +418,7 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
   const int grid = (int)(wgs < cus ? wgs : cus);
   auto launch = [&](auto kern, size_t lds) -> int {
     if (lds > 160 * 1024) {
-      set_error("sasrec_last_row: S = %d needs %zu bytes of LDS (> 160 KiB)", S, lds);
+      set_error("sasrec_last_row: S = %d with %d candidates needs %zu bytes of LDS (> 160 KiB)", S, n_pos + n_neg, lds);
       return REC_ENOTIMPL;
     }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -388,11 +429,11 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds, st, P, seq_table, seq_vocab, seq_ids, seq_ids_stride,
                        (int)S, pad_id, mask_ids, mask_stride, pos_table, pos_vocab, pos_ids, pos_ids_stride, (int)n_pos,
                        neg_table, neg_vocab, neg_ids, neg_ids_stride, (int)n_neg, B, seq_info, logits, logits_stride,
-                       reinterpret_cast<int*>(oob_flag), lst_cap);
+                       reinterpret_cast<int*>(oob_flag), lst_cap, cand_cap);
     return REC_OK;
   };
-  int rc = blk->ffn_hidden == 128 ? launch(sasrec_last_row_kernel<128>, lds_bytes<128>(lst_cap))
-                                  : launch(sasrec_last_row_kernel<64>, lds_bytes<64>(lst_cap));
+  int rc = blk->ffn_hidden == 128 ? launch(sasrec_last_row_kernel<128>, lds_bytes<128>(lst_cap, cand_cap))
+                                  : launch(sasrec_last_row_kernel<64>, lds_bytes<64>(lst_cap, cand_cap));
   if (rc != REC_OK) return rc;
   REC_CHECK_LAUNCH("sasrec_last_row");
   return REC_OK;

@@ -151,7 +151,7 @@ class SASRec(Model):
         if enc.mha.num_heads != 1 or any(t.dtype != torch.int32 for t in (seq_inputs, pos_inputs, neg_inputs)):
             return None
         ffn_hidden = enc.ffn.conv1.units
-        if not ops.sasrec_last_row_supported(self.d_model, ffn_hidden, S):
+        if not ops.sasrec_last_row_supported(self.d_model, ffn_hidden, S, pos_inputs.shape[1] + neg_inputs.shape[1]):
             return None
         d = self.d_model
         for layer, n_in in ((enc.mha.wq, d), (enc.mha.wk, d), (enc.mha.wv, d), (enc.ffn.conv1, d), (enc.ffn.conv2, ffn_hidden),

@@ -426,9 +426,10 @@ def gather_dot_scores(seq_info: torch.Tensor, table: torch.Tensor, ids: torch.Te
     return out
 
 
-def sasrec_last_row_supported(d_model: int, ffn_hidden: int, S: int) -> bool:
-    """Shapes served by the one-launch SASRec kernel (rec_sasrec_last_row_f32)."""
-    return d_model == 64 and ffn_hidden in (64, 128) and 1 <= S <= 512
+def sasrec_last_row_supported(d_model: int, ffn_hidden: int, S: int, n_cand: int) -> bool:
+    """Shapes served by the one-launch SASRec kernel (rec_sasrec_last_row_f32): d 64, ffn 64 / 128, id buffers that fit
+    the LDS next to the block's weights."""
+    return bool(C.sasrec_last_row_supported(int(d_model), int(ffn_hidden), int(S), int(n_cand)))
 
 
 def sasrec_last_row(weights, eps1, eps2, seq_table, seq_ids, pad_id, mask_ids, mask_stride, pos_table, pos_ids, neg_table,

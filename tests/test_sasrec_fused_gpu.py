@@ -44,7 +44,7 @@ def run(dev, P, T, seq, pos, neg, pad_id=0, eps=1e-6, flag=None):
 
 
 @pytest.mark.parametrize("B,S,n_neg,fh", [(40, 20, 100, 128), (7, 1, 1, 64), (33, 5, 31, 128), (19, 64, 32, 64),
-                                          (21, 65, 33, 128), (16, 200, 100, 128), (5, 512, 130, 128), (130, 37, 63, 64)])
+                                          (21, 65, 33, 128), (16, 200, 100, 128), (5, 256, 128, 128), (9, 320, 130, 64), (130, 37, 63, 64)])
 def test_matches_the_oracle(dev, B, S, n_neg, fh):
     rng = np.random.default_rng(B * 1000 + S)
     P, T, seq, pos, neg = make_case(rng, B, S, n_neg, 300, fh)
@@ -142,4 +142,5 @@ def test_rejects_unsupported_shapes(dev):
     P["W2"] = np.zeros((192, 64), np.float32)
     with pytest.raises(RuntimeError, match="ffn_hidden"):
         run(dev, P, T, seq, pos, neg)
-    assert not ops.sasrec_last_row_supported(32, 128, 10) and not ops.sasrec_last_row_supported(64, 128, 2000)
+    assert not ops.sasrec_last_row_supported(32, 128, 10, 5) and not ops.sasrec_last_row_supported(64, 128, 2000, 5)
+    assert ops.sasrec_last_row_supported(64, 128, 200, 101)
