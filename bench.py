@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=16384)
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (gather_roofline, rowshard)")
     ap.add_argument("--side-timeout", type=float, default=240.0, help="watchdog of the N>1 side placement measurement (s)")
+    ap.add_argument("--side-leg", action="store_true", help=argparse.SUPPRESS)   # internal: child process of an N>1 run
     return ap.parse_args()
 
 
@@ -256,17 +257,68 @@ def wl_sasrec(torch, dev, a, rank, world):
             "config": {"batch_per_gpu": B, "global_batch": B * world, "seq_len": S, "neg_len": n, "d": d,
                        "vocab_per_table": V, "mean_real_positions": round(real / NB / B, 2),
                        "bytes_note": "item rows of real positions + pos/neg rows + ids + logits"},
-            "side_gather": None, "shape_cfg": {}}
+            "side_gather": None, "shape_cfg": {}, "sharded": getattr(m, "_sharded", None)}
+
+
+SIDE_WORKLOADS = ("dlrm_fused", "gather", "sasrec")
+
+
+def spawn_side_leg(a):
+    """At N > 1 the OTHER table placement is measured in the same run and reported beside the headline — in a CHILD
+    process per rank, started before this process touches the GPU and parked on its stdin until the headline is done.
+    A collective that hangs or a communicator that aborts then costs the `rowshard` object, never the headline line.
+    The children rendezvous among themselves on their own port."""
+    import subprocess
+    alt = "rowshard" if a.placement == "replicated" else "replicated"
+    argv, skip = [], False
+    for tok in sys.argv[1:]:
+        if skip:
+            skip = False
+        elif tok == "--placement":
+            skip = True
+        elif not tok.startswith("--placement="):
+            argv.append(tok)
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 137)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k.startswith("TORCH_NCCL_ASYNC")]:
+        env.pop(k)
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--placement", alt, "--side-leg", "--no-side", "--cpu-seconds", "0"]
+    proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+    return alt, proc
+
+
+def collect_side_leg(alt, proc, timeout):
+    """Release the parked child, wait for its line (rank 0's child prints one), kill exactly that child on timeout."""
+    import subprocess
+    try:
+        out, err = proc.communicate("go\n", timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"placement": alt, "error": f"timed out after {timeout:.0f} s"}
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        tail = (err or "").strip().splitlines()[-3:]
+        return {"placement": alt, "error": f"side process rc={proc.returncode}: " + " | ".join(tail)[:400]}
+    r = json.loads(lines[-1])
+    return {"placement": alt, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+            "launch_us": r["roofline"]["launch_us"], "exchange": r["config"].get("exchange")}
 
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    side = None
+    if a.side_leg:
+        if not sys.stdin.readline().startswith("go"):     # parked until the parent has printed-ready its headline
+            return
+    elif world > 1 and not a.no_side and a.workload in SIDE_WORKLOADS:
+        side = spawn_side_leg(a)
+    import torch
+    import torch.distributed as dist
+
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -293,6 +345,18 @@ def main():
 
     def build(wl, placement):
         a.placement = placement
+        if placement == "rowshard" and world > 1 and "REC_SHARD_TRANSPORT" not in os.environ:
+            # the library's own RCCL communicator first; if it cannot be created here, the same exchange over
+            # torch.distributed's collectives (every rank takes the same branch: the failure modes are per-node)
+            try:
+                return build_(wl)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: C-ABI transport failed ({type(e).__name__}: {e}); using torch.distributed",
+                      file=sys.stderr, flush=True)
+                os.environ["REC_SHARD_TRANSPORT"] = "torch"
+        return build_(wl)
+
+    def build_(wl):
         if wl == "dlrm_fused":
             return wl_dlrm(torch, dev, a, rank, world, fused=True)
         if wl == "gather":
@@ -432,35 +496,15 @@ def main():
         if pcie is not None:
             res["pcie_inclusive"] = pcie
 
-    # At N > 1 the OTHER placement is measured in the same run and reported beside the headline.  It runs under a
-    # watchdog: a collective that hangs must not cost the headline line (rank 0 prints what it has, every rank exits).
-    if not a.no_side and world > 1 and a.workload in ("dlrm_fused", "gather", "sasrec"):
-        import threading
-        first_placement = a.placement
-        alt = "rowshard" if first_placement == "replicated" else "replicated"
-
-        def give_up():
-            if rank == 0:
-                res[alt] = {"placement": alt, "error": f"timed out after {a.side_timeout:.0f} s"}
-                print(json.dumps(res), flush=True)
-            os._exit(0)
-        dog = threading.Timer(a.side_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            del w
-            torch.cuda.empty_cache()
-            w2 = build(a.workload, alt)
-            wall2, dev2, launch2 = measure(w2)
-            other = {"placement": alt, "value": round(world * w2["units"] * a.steps / wall2, 1), "unit": "samples/s",
-                     "ms_per_step": round(wall2 / a.steps * 1e3, 4), "launch_us": launch2,
-                     "exchange": w2["sharded"].describe() if w2.get("sharded") is not None else None}
-        except Exception as e:  # noqa: BLE001  (a failing side measurement must not cost the headline line)
-            other = {"placement": alt, "error": f"{type(e).__name__}: {e}"[:300]}
-        dog.cancel()
-        a.placement = first_placement
+    # At N > 1: release the parked child processes (spawn_side_leg) once every rank has finished the headline and
+    # returned its tables to the allocator; ranks other than 0 only wait for their child to end.
+    if side is not None:
+        del w
+        torch.cuda.empty_cache()
+        barrier()
+        other = collect_side_leg(side[0], side[1], a.side_timeout)
         if rank == 0:
-            res[alt] = other
+            res[side[0]] = other
 
     if rank == 0:
         print(json.dumps(res), flush=True)

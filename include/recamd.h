@@ -514,6 +514,11 @@ int rec_binary_crossentropy_f32(const float* y_true, const float* y_pred, int64_
                                 void* workspace, void* stream);
 int rec_auc_f32(const float* y_true, const float* y_pred, int64_t n, float* out, void* workspace,
                 void* stream);
+/* add_loss of the match models (src/match/sasrec/model.py:93-95, src/match/ncf/model.py:75-77): logits (B, 1 + n_neg)
+ * with column 0 = positive score; out[0] = mean over (b, j) of [-log sigmoid(pos_b) - log(1 - sigmoid(neg_bj))] / 2.
+ * workspace: rec_metrics_workspace_bytes(B * n_neg) bytes. */
+int rec_pairwise_rank_loss_f32(const float* logits, int64_t logits_stride, int64_t B, int32_t n_neg, float* out,
+                               void* workspace, void* stream);
 
 /* ---- §8f-4: retrieval after the towers — exact inner-product top-k ---------------------------------
  * Replaces faiss.IndexFlatIP(d).add(items).search(queries, k) of src/match/dssm/dssm_train.py:74-78 and

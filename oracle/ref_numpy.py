@@ -602,6 +602,14 @@ def keras_auc(y_true, y_pred, num_thresholds=200):
     return float(np.sum((fpr[:-1] - fpr[1:]).astype(np.float32) * ((tpr[:-1] + tpr[1:]) * np.float32(0.5))))
 
 
+def pairwise_rank_loss(logits, dtype=np.float64):
+    """add_loss of src/match/sasrec/model.py:93-95 and src/match/ncf/model.py:75-77 on logits (B, 1+n), column 0 = pos:
+    reduce_mean(-log(sigmoid(pos)) - log(1 - sigmoid(neg))) / 2 with (B,1) + (B,n) broadcasting."""
+    lg = np.asarray(logits, dtype)
+    pos, neg = lg[:, :1], lg[:, 1:]
+    return np.mean(-np.log(sigmoid(pos)) - np.log(1 - sigmoid(neg))) / 2
+
+
 def match_fm_forward(user_ids, item_ids, user_tables, item_tables, w0, w, V, dtype=np.float64):
     """src/match/fm/model.py:62-83: stack = [user embeddings, item embeddings]; sigmoid(w0 + stack w +
     0.5 sum_k((stack V^T)_k^2 - (stack^2 (V^T)^2)_k)).  Returns (out (B,1), user_embeds, item_embeds)."""

@@ -41,6 +41,35 @@ __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restric
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// add_loss of the match models (src/match/sasrec/model.py:93-95, src/match/ncf/model.py:75-77):
+//   mean over (b, j) of [-log sigmoid(pos[b, 0]) - log(1 - sigmoid(neg[b, j]))] / 2   ((B,1) + (B,n) broadcasting)
+// logits (B, 1 + n): column 0 = pos, columns 1.. = neg.  Written as the reference writes it (sigmoid, then log): a
+// saturated score gives the same +inf TensorFlow gives.
+__global__ __launch_bounds__(256) void pair_loss_partial_kernel(const float* __restrict__ logits, int64_t stride,
+                                                                int64_t B, int n, double* __restrict__ part) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const int64_t total = B * (int64_t)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / n;
+    const int j = (int)(i - b * n);
+    const float sp = 1.f / (1.f + expf(-logits[b * stride]));
+    const float sn = 1.f / (1.f + expf(-logits[b * stride + 1 + j]));
+    acc += (double)(-logf(sp) - logf(1.f - sn));
+  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void pair_loss_finish_kernel(const double* __restrict__ part, int nblk, int64_t n, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[i];
+  out[0] = (float)(s / (double)n * 0.5);
+}
+
 __global__ void bce_finish_kernel(const double* __restrict__ part, int nblk, int64_t n, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double s = 0.0;
@@ -119,6 +148,22 @@ extern "C" int rec_binary_crossentropy_f32(const float* y_true, const float* y_p
                      static_cast<double*>(workspace));
   hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, st, static_cast<const double*>(workspace), blocks, n,
                      out);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_pairwise_rank_loss_f32(const float* logits, int64_t logits_stride, int64_t B, int32_t n_neg, float* out,
+                                          void* workspace, void* stream) {
+  const char* who = "rec_pairwise_rank_loss_f32";
+  REC_CHECK_ARG(B >= 1 && n_neg >= 1 && logits_stride >= 1 + n_neg, REC_ESHAPE, "%s: B=%lld n_neg=%d stride=%lld", who,
+                (long long)B, n_neg, (long long)logits_stride);
+  REC_CHECK_ARG(logits && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = metric_blocks(B * (int64_t)n_neg);
+  hipLaunchKernelGGL(pair_loss_partial_kernel, dim3(blocks), dim3(256), 0, st, logits, logits_stride, B, (int)n_neg,
+                     static_cast<double*>(workspace));
+  hipLaunchKernelGGL(pair_loss_finish_kernel, dim3(1), dim3(64), 0, st, static_cast<const double*>(workspace), blocks,
+                     B * (int64_t)n_neg, out);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }

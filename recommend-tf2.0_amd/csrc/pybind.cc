@@ -587,5 +587,10 @@ PYBIND11_MODULE(_C, m) {
                                   logits_stride, P<int32_t>(oob), P<void>(stream)),
           "rec_sasrec_last_row_f32");
   });
+  m.def("pairwise_rank_loss_f32", [](ptr_t logits, int64_t stride, int64_t B, int n_neg, ptr_t out, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_pairwise_rank_loss_f32(P<const float>(logits), stride, B, n_neg, P<float>(out), P<void>(ws), P<void>(stream)),
+          "rec_pairwise_rank_loss_f32");
+  });
 }
 

@@ -47,20 +47,21 @@ class DLRM(Model):
         dense_inputs = to_device_f32(dense_inputs, self.device)
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
         B = sparse_inputs.shape[0]
-        dense_fea = self.bot_dnn(dense_inputs)                                 # intended :44
         if self.interaction == 'dot':
+            dense_fea = self.bot_dnn(dense_inputs)                             # intended :44
             x = ops.gather_pairwise_dot(self._group, sparse_inputs, dense_fea, append_dense=True)
         else:
-            # tf.concat([sparse_embed, dense_fea]) (:48) without a copy: the gather writes the sparse part
-            # of one (B, sum D + bot) buffer, the bottom MLP's last layer wrote its tail
+            # tf.concat([sparse_embed, dense_fea]) (:48) without a copy: the gather writes the sparse part of one
+            # (B, sum D + bot) buffer and the bottom MLP's last layer writes its tail (16-B aligned tail: directly;
+            # otherwise through one strided copy kernel)
             W = self._group.width
-            Hb = dense_fea.shape[1]
+            Hb = self.bot_dnn.dnn_network[-1].units
+            buf = torch.empty((B, W + Hb + ((-(W + Hb)) % 4)), dtype=torch.float32, device=self.device)
+            ops.gather_concat(self._group, sparse_inputs, out=buf)                 # :45
             if W % 4 == 0:
-                buf = torch.empty((B, W + Hb + ((-Hb) % 4)), dtype=torch.float32, device=self.device)
-                ops.gather_concat(self._group, sparse_inputs, out=buf)             # :45
-                buf[:, W:W + Hb] = dense_fea
-                x = buf[:, :W + Hb]
+                self.bot_dnn(dense_inputs, out=buf[:, W:W + Hb])                   # intended :44
             else:
-                x = torch.cat([ops.gather_concat(self._group, sparse_inputs), dense_fea], dim=-1)
+                ops.copy_cols(self.bot_dnn(dense_inputs), buf[:, W:])
+            x = buf[:, :W + Hb]
         top = self.final_dense(self.top_dnn(x))                                # intended :50-51
         return ops.add_sigmoid(top)                                            # :53

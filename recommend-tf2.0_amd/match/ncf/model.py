@@ -1,8 +1,8 @@
 """Mirror of src/match/ncf/model.py (NeuMF: GMF + MLP over user / positive / negative item embeddings).
 
 call([user (B,1), pos (B,1), neg (B,neg_num)]) -> logits (B, 1 + neg_num) = concat([pos_logits, neg_logits]) (:79).
-The reference adds its BCE loss with `add_loss` (:75-78): training harness, not built here; the
-forward returns the logits that loss is computed from.  Note the GMF and MLP
+The reference adds its BCE-style loss with `add_loss` (:75-78): available as `model.losses` after a call
+(rec_pairwise_rank_loss_f32); the forward returns the logits that loss is computed from.  Note the GMF and MLP
 parts share the SAME embeddings (`mlp_*_embed = self.*_embedding(...)`, :57-59), and the negative items have their
 own table `neg_item_embedding` (:38-42)."""
 import torch
@@ -46,4 +46,12 @@ class NCF(Model):
         neg, _, Tn = self._lookup(self.neg_item_embedding, neg_inputs)
         pos_logits = self._branch(user, pos, B, Tp)
         neg_logits = self._branch(user, neg, B, Tn)
-        return torch.cat([pos_logits, neg_logits], dim=-1)                              # :79
+        self._logits = torch.cat([pos_logits, neg_logits], dim=-1)                      # :79
+        return self._logits
+
+    @property
+    def losses(self):
+        """[mean(-log sigmoid(pos) - log(1 - sigmoid(neg))) / 2] of the last call (the add_loss of :75-77), computed on
+        demand by rec_pairwise_rank_loss_f32 (pos_num = 1, as in the reference's data)."""
+        lg = getattr(self, '_logits', None)
+        return [] if lg is None else [ops.pairwise_rank_loss(lg)[0]]

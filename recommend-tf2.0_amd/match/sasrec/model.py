@@ -170,5 +170,4 @@ class SASRec(Model):
         (B,1) + (B,neg) broadcasting).  Lazy: a forward pass used for scoring does not pay for it."""
         if self._logits is None:
             return []
-        pos_scores, neg_scores = self._logits[:, :1], self._logits[:, 1:]
-        return [torch.mean(-torch.log(torch.sigmoid(pos_scores)) - torch.log(1 - torch.sigmoid(neg_scores))) / 2]
+        return [ops.pairwise_rank_loss(self._logits)[0]]

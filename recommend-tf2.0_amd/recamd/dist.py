@@ -170,6 +170,9 @@ class ShardedTables:
         self._shift = (torch.arange(self.F, dtype=torch.int32, device=dev) * self.vpad)[None, :]
         self._vocab_t = torch.tensor(self.vocabs, dtype=torch.int32, device=dev)[None, :]
         if transport is None:
+            import os
+            transport = os.environ.get("REC_SHARD_TRANSPORT") or None      # 'cabi' | 'torch': overrides the default below
+        if transport is None:
             is_nccl = world > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
             transport = "cabi" if (is_nccl and kernels is None and dev.type == "cuda") else "torch"
         if transport not in ("cabi", "torch", "peers"):

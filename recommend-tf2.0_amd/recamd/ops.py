@@ -756,6 +756,19 @@ def binary_crossentropy(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Ten
     return out
 
 
+def pairwise_rank_loss(logits: torch.Tensor) -> torch.Tensor:
+    """add_loss of SASRec / NCF (src/match/sasrec/model.py:93-95): logits (B, 1 + n), column 0 = the positive score ->
+    mean(-log sigmoid(pos) - log(1 - sigmoid(neg))) / 2 with (B,1)+(B,n) broadcasting, shape (1,)."""
+    _rows2d(_chk(logits, "logits"), "logits")
+    B, w = logits.shape
+    if w < 2:
+        raise ValueError("pairwise_rank_loss: logits need a positive column and at least one negative column")
+    ws = torch.empty(int(C.metrics_workspace_bytes(B * (w - 1))), dtype=torch.uint8, device=logits.device)
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    C.pairwise_rank_loss_f32(logits.data_ptr(), logits.stride(0), B, w - 1, out.data_ptr(), ws.data_ptr(), _stream())
+    return out
+
+
 def auc(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
     """tf.keras.metrics.AUC() with its defaults (200 thresholds, ROC, trapezoid) -> shape (1,)."""
     y_true, y_pred, ws, out = _metric_args(y_true, y_pred)

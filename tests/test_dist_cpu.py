@@ -100,6 +100,60 @@ def test_sharded_lookup_backward_allreduce_gloo(world, vocabs, D, B, dedup):
     assert all(ret.get(r) for r in range(world)), ret
 
 
+def _sasrec_worker(rank, world, port, V, S, n_neg, B, ret):
+    """BASELINE configs[4] through the exchange: the seq / pos / neg lookups of src/match/sasrec/model.py:75-79 travel
+    as ONE sharded lookup (pad id 0 dropped before it); the rows read back through uidx feed the oracle's encoder and
+    must give the logits of the oracle's sasrec_forward on the UNSHARDED tables."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_numpy as ref
+        from recamd.dist import ShardedTables, shard_table
+        from tests.shard_oracle import OracleKernels
+        d = 64
+        rng = np.random.default_rng(7)                      # same tables and weights on every rank
+        T = [rng.normal(size=(V, d)).astype(np.float32) * 0.3 for _ in range(3)]
+        P = dict(Wq=rng.normal(size=(d, d)) * 0.1, bq=rng.normal(size=d) * 0.1, Wk=rng.normal(size=(d, d)) * 0.1,
+                 bk=rng.normal(size=d) * 0.1, Wv=rng.normal(size=(d, d)) * 0.1, bv=rng.normal(size=d) * 0.1,
+                 W1=rng.normal(size=(d, 128)) * 0.1, b1=rng.normal(size=128) * 0.1, W2=rng.normal(size=(128, d)) * 0.1,
+                 b2=rng.normal(size=d) * 0.1, ln1_g=np.ones(d), ln1_b=np.zeros(d), ln2_g=np.ones(d), ln2_b=np.zeros(d))
+        r2 = np.random.default_rng(100 + rank)              # every rank its own batch
+        lens = r2.integers(0, S + 1, size=B)
+        seq = r2.integers(1, V, size=(B, S))
+        seq[np.arange(S)[None, :] < (S - lens)[:, None]] = 0
+        seq, pos, neg = seq.astype(np.int32), r2.integers(0, V, size=(B, 1)).astype(np.int32), \
+            r2.integers(0, V, size=(B, n_neg)).astype(np.int32)
+        st = ShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in T], [V] * 3, rank, world,
+                           kernels=OracleKernels(True), dedup=True)
+        ts, tp, tn = (torch.from_numpy(a) for a in (seq, pos, neg))
+        vids = torch.cat([st.virtual_ids(0, ts, pad_id=0).reshape(-1), st.virtual_ids(1, tp).reshape(-1),
+                          st.virtual_ids(2, tn).reshape(-1)])
+        rows, uidx = st.lookup_rows(vids)
+        rows, uidx = rows.numpy(), uidx.numpy()
+        got = np.where((uidx >= 0)[:, None], rows[np.maximum(uidx, 0)], 0.0).astype(np.float32)
+        seq_e = got[:B * S].reshape(B, S, d)
+        pos_e = got[B * S:B * S + B].reshape(B, 1, d)
+        neg_e = got[B * S + B:].reshape(B, n_neg, d)
+        mask = (seq != 0).astype(np.float32)[..., None]
+        ok = bool(np.array_equal(seq_e, T[0][seq] * mask)) and bool(np.array_equal(pos_e, T[1][pos])) and \
+            bool(np.array_equal(neg_e, T[2][neg]))                      # bit-exact rows, pads as zero rows
+        ok = ok and st.stats["unique_sent"] <= int((seq != 0).sum()) + B + B * n_neg      # pads were never sent
+        x = ref.transformer_encoder(seq_e.astype(np.float64) * mask, mask, P, 1) * mask
+        si = x[:, -1][:, None, :]
+        logits = np.concatenate([np.sum(si * pos_e, -1), np.sum(si * neg_e, -1)], -1)
+        exp, _ = ref.sasrec_forward(seq, pos, neg, T[0], T[1], T[2], [P], 1)
+        ok = ok and bool(np.allclose(logits, exp, rtol=1e-12, atol=1e-12))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sasrec_lookups_through_the_exchange_gloo():
+    ret = _spawn(_sasrec_worker, 2, 700, 200, 20, 9)
+    assert all(ret.get(r) for r in range(2)), ret
+
+
 def test_shard_helpers():
     from recamd.dist import local_rows_of, shard_table
     t = torch.arange(10 * 2, dtype=torch.float32).view(10, 2)

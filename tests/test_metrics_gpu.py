@@ -55,3 +55,19 @@ def test_perfect_and_random_rankings(dev):
     assert abs(float(ops.auc(torch.from_numpy(y).to(dev), torch.from_numpy(perfect).to(dev)).cpu()) - 1.0) <= 1e-6
     const = np.full_like(y, 0.5)
     assert abs(float(ops.auc(torch.from_numpy(y).to(dev), torch.from_numpy(const).to(dev)).cpu()) - 0.5) <= 1e-6
+
+
+@pytest.mark.parametrize("B,n,stride_pad", [(1, 1, 0), (37, 100, 0), (513, 7, 3), (4096, 100, 0)])
+def test_pairwise_rank_loss(dev, B, n, stride_pad):
+    """rec_pairwise_rank_loss_f32 vs the restated add_loss of src/match/sasrec/model.py:93-95 (also NCF :75-77)."""
+    from recamd import ops
+    rng = np.random.default_rng(B + n)
+    lg = (rng.normal(size=(B, 1 + n)) * 2).astype(np.float32)
+    wide = torch.zeros((B, 1 + n + stride_pad), dtype=torch.float32, device=dev)
+    wide[:, :1 + n] = torch.from_numpy(lg).to(dev)
+    got = float(ops.pairwise_rank_loss(wide[:, :1 + n])[0])
+    exp = float(ref.pairwise_rank_loss(lg))
+    assert abs(got - exp) <= 1e-5 * max(1.0, abs(exp))
+    # the sasrec oracle computes the same number from its own logits
+    assert abs(exp - float(np.mean(-np.log(ref.sigmoid(lg[:, :1].astype(np.float64))) -
+                                   np.log(1 - ref.sigmoid(lg[:, 1:].astype(np.float64)))) / 2)) < 1e-12

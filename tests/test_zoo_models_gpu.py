@@ -161,6 +161,8 @@ def test_ncf(dev, neg):
                           w['neg_item_embedding/embeddings'], layers, (w['dense/kernel'], w['dense/bias']))
     assert out.shape == (B, 1 + neg)
     assert close(out, exp)
+    loss = ref.pairwise_rank_loss(exp)                                  # the add_loss of src/match/ncf/model.py:75-77
+    assert abs(float(m.losses[0]) - loss) <= 1e-5 * max(1.0, abs(loss))
 
 
 @pytest.mark.parametrize("D", [8, 6])
