@@ -152,7 +152,7 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
     }
     if fused:
         w.update(step=step_fused, work=bytes_fused,
-                 kernel="rec::pairdot_ring_kernel<27, true, true, 2, 4, 0, 3> (LDS-DMA ring + fp32 MFMA: fused gather + "
+                 kernel="rec::pairdot_ring_kernel<27, true, true, 2, 4, 0, 15> (LDS-DMA ring + fp32 MFMA, write-through result stores: fused gather + "
                         "pairwise dot)" if sharded is None else "row-sharded lookup (RCCL all-to-all pair) + pairwise dot",
                  pmc_key="pairdot_ring_kernel",
                  workload="DLRM 26 sparse x 1M vocab x dim 128, batch 65536/GPU: fused embedding gather + pairwise-dot "

@@ -43,6 +43,23 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1)))* gsrc_t;
 typedef u32x4 __attribute__((address_space(1)))* gdst_t;
 
+// output store of a 16-B row piece.  REC_GATHER_STORE selects the cache policy (A/B builds): 0 = nontemporal,
+// 1 = sc0 sc1 (system-scope write-through), 2 = sc0 sc1 nt, 3 = sc1
+#ifndef REC_GATHER_STORE
+#define REC_GATHER_STORE 0
+#endif
+__device__ __forceinline__ void row_store(u32x4 v, uint64_t addr) {
+#if REC_GATHER_STORE == 0
+  __builtin_nontemporal_store(v, reinterpret_cast<gdst_t>(addr));
+#elif REC_GATHER_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(addr), "v"(v) : "memory");
+#elif REC_GATHER_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(addr), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(addr), "v"(v) : "memory");
+#endif
+}
+
 template <int LPR, int IDS_F32>
 __global__ __launch_bounds__(256) void gather_uniform_kernel(
     TableSet ts, const void* __restrict__ ids, int64_t ids_stride, int F, int64_t R,
@@ -101,12 +118,11 @@ __global__ __launch_bounds__(256) void gather_uniform_kernel(
     }
     if (full) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        __builtin_nontemporal_store(v[u], reinterpret_cast<gdst_t>(d[u] + col * 4));
+      for (int u = 0; u < U; ++u) row_store(v[u], d[u] + col * 4);
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (d[u]) __builtin_nontemporal_store(v[u], reinterpret_cast<gdst_t>(d[u] + col * 4));
+        if (d[u]) row_store(v[u], d[u] + col * 4);
     }
   }
 }

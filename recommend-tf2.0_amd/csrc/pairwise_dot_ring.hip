@@ -39,70 +39,53 @@ __device__ __attribute__((aligned(512))) float g_ring_zero_row[128];
 // LDS-DMA burst, 16 B per lane and piece: LDS[lds + 1024*t + 16*lane] <- *g[t], t < NP, back to back (one asm
 // statement: nothing is scheduled between the pieces, M0 = destination base is stepped in place; the s_nop 0 is the
 // SALU-writes-M0 -> LDS-DMA wait state).  NT: streaming policy for rows that are read once.
-template <int NP, bool NT>
+// LM: cache policy of the row loads — 0 default, 1 nt (streaming; shipped); experiment builds: 2 sc1 nt, 3 sc0 sc1 nt,
+// 4 sc1, 5 sc0 sc1
+#define REC_BURST_PIECE_(i, SUF) "s_nop 0\n\tglobal_load_lds_dwordx4 %" #i ", off" SUF "\n\ts_add_u32 m0, m0, 0x400\n\t"
+#define REC_BURST14_(SUF)                                                                                              \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" REC_BURST_PIECE_(2, SUF) REC_BURST_PIECE_(3, SUF)             \
+                   REC_BURST_PIECE_(4, SUF) REC_BURST_PIECE_(5, SUF) REC_BURST_PIECE_(6, SUF) REC_BURST_PIECE_(7, SUF)  \
+                       REC_BURST_PIECE_(8, SUF) REC_BURST_PIECE_(9, SUF) REC_BURST_PIECE_(10, SUF)                      \
+                           REC_BURST_PIECE_(11, SUF) REC_BURST_PIECE_(12, SUF) REC_BURST_PIECE_(13, SUF)                \
+                               REC_BURST_PIECE_(14, SUF) "s_nop 0\n\tglobal_load_lds_dwordx4 %15, off" SUF "\n\t"      \
+                                                         "s_mov_b32 m0, %0"                                            \
+               : "=&s"(keep)                                                                                           \
+               : "s"(lds), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]),     \
+                 "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "v"(g[12]), "v"(g[13])                                  \
+               : "memory")
+#define REC_BURST1_(SUF)                                                                                               \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SUF               \
+               "\n\ts_mov_b32 m0, %0"                                                                                  \
+               : "=&s"(keep)                                                                                           \
+               : "v"(g[t]), "s"(lds + 1024u * t)                                                                       \
+               : "memory")
+template <int NP, int LM>
 __device__ __forceinline__ void glds16_burst(const uint64_t (&g)[16], uint32_t lds) {
   static_assert(NP >= 1 && NP <= 16, "");
-#define REC_P_(i) "s_nop 0\n\tglobal_load_lds_dwordx4 %" #i ", off%V\n\ts_add_u32 m0, m0, 0x400\n\t"
   // operand 0 = saved M0, 1 = lds base, 2.. = piece addresses
   if constexpr (NP == 14) {
     unsigned keep;
-    if constexpr (NT)
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %3, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %4, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %5, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %6, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %7, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %8, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %9, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %10, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %11, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %12, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %13, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %14, off nt\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %15, off nt\n\t"
-                   "s_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "s"(lds), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]),
-                     "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "v"(g[12]), "v"(g[13])
-                   : "memory");
-    else
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %7, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %8, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %9, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %10, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %11, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %12, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %13, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %14, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                   "s_nop 0\n\tglobal_load_lds_dwordx4 %15, off\n\t"
-                   "s_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "s"(lds), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]),
-                     "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "v"(g[12]), "v"(g[13])
-                   : "memory");
+    if constexpr (LM == 1) REC_BURST14_(" nt");
+    else if constexpr (LM == 0) REC_BURST14_("");
+#ifdef REC_RING_EXPERIMENTS
+    else if constexpr (LM == 2) REC_BURST14_(" sc1 nt");
+    else if constexpr (LM == 3) REC_BURST14_(" sc0 sc1 nt");
+    else if constexpr (LM == 4) REC_BURST14_(" sc1");
+    else REC_BURST14_(" sc0 sc1");
+#endif
   } else {
     // other row counts: one statement per piece (same instructions, the compiler may schedule between them)
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       unsigned keep;
-      if constexpr (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(g[t]), "s"(lds + 1024u * t) : "memory");
-      else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(g[t]), "s"(lds + 1024u * t) : "memory");
+      if constexpr (LM == 0) REC_BURST1_("");
+      else REC_BURST1_(" nt");
     }
   }
-#undef REC_P_
 }
+#undef REC_BURST1_
+#undef REC_BURST14_
+#undef REC_BURST_PIECE_
 // LDS-DMA, 4 B per lane
 __device__ __forceinline__ void glds4(const void* g, uint32_t lds) {
   unsigned keep;
@@ -118,12 +101,28 @@ __device__ __forceinline__ void gstore16_nt(void* p, f32x4 v) {
 __device__ __forceinline__ void gstore16(void* p, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
+// result stores with scope bits (POL bits 2-4).  Shipped: sc0 sc1 = system-scope write-through — the 126 MB of results
+// leave the L2 as they are written instead of sitting there as dirty lines that are evicted in bursts between the
+// streaming row reads: 184.8 -> 176 us on one box, 174.6 -> 168 us on another (profiles/r02_ring_store_ab.txt);
+// sc1 alone 177; sc0 alone = plain; any of them with nt 188.
+template <int SP>
+__device__ __forceinline__ void gstore16_scope(void* p, f32x4 v) {
+  if constexpr (SP == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else if constexpr (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else if constexpr (SP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else if constexpr (SP == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 #define REC_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n) : "memory")
 #define REC_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory")
 
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
+
+// POL: bit 0 = streaming row loads, bit 1 = plain (not nt) result stores; experiment builds: bits 2-4 = store scope
+// arm, bits 5-7 = load policy arm
+constexpr int load_mode(int pol) { return (pol >> 5) ? (pol >> 5) + 1 : (pol & 1); }
 
 // N rows per sample (F table rows + the dense row if HAS_DENSE), S ring slots per wave, WPB waves per block.
 template <int N, bool HAS_DENSE, bool APPEND, int S, int WPB, int ABL, int POL>
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(WPB * 64, 1) void pairdot_ring_kernel(
     row_addrs(p, g);
     REC_LGKMCNT0();
     issue_ids(p + 1);
-    glds16_burst<NDMA, (POL & 1) != 0>(g, lds_base + (uint32_t)(p * SLOT));
+    glds16_burst<NDMA, load_mode(POL)>(g, lds_base + (uint32_t)(p * SLOT));
   }
 
   for (int k0 = 0; k0 < nk; k0 += S) {
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(WPB * 64, 1) void pairdot_ring_kernel(
       // refill this slot with sample k + S as soon as its operands are in registers; request the ids after that
       REC_LGKMCNT0();
       issue_ids(k + S + 1);
-      glds16_burst<NDMA, (POL & 1) != 0>(g, lds_base + (uint32_t)(s * SLOT));
+      glds16_burst<NDMA, load_mode(POL)>(g, lds_base + (uint32_t)(s * SLOT));
       // keep the matrix work below the burst (an MFMA is a register-only instruction: nothing else orders it)
       asm volatile("" : "+v"(x0[0]), "+v"(x1[0]));
 
@@ -302,7 +301,8 @@ __global__ __launch_bounds__(WPB * 64, 1) void pairdot_ring_kernel(
         int g = lane + 64 * u;
         g = g < W4 ? g : W4 - 1;  // surplus lanes repeat the last group
         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * g);
-        if constexpr (POL & 2) gstore16(orow + g, v);
+        if constexpr (((POL >> 2) & 7) != 0) gstore16_scope<((POL >> 2) & 7)>(orow + g, v);
+        else if constexpr (POL & 2) gstore16(orow + g, v);
         else gstore16_nt(orow + g, v);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(WPB * 64, 1) void pairdot_ring_kernel(
   if (bad && oob_flag) *oob_flag = 1;
 }
 
-template <int N, bool HAS_DENSE, bool APPEND, int S, int WPB, int ABL = 0, int POL = 3>
+template <int N, bool HAS_DENSE, bool APPEND, int S, int WPB, int ABL = 0, int POL = 15>
 static bool launch_ring(const TableSet& ts, const int32_t* ids, int64_t ids_stride, const float* dense,
                         int64_t dense_stride, int B, float* out, int64_t out_stride, int* oob, int blocks_per_cu,
                         int cus, hipStream_t st) {
@@ -358,7 +358,8 @@ bool pairdot128_ring_dispatch(const TableSet& ts, int F, bool has_dense, int ids
   if (out_stride < (P + (append_dense ? 128 : 0) + 3) / 4 * 4) return false;
   // Ring geometry (measured on MI355X, 65 536 x 27 x 128, rotating id batches, after spin-up; tools/exp/ring_ab.py,
   // profiles/r02_ring_ab.txt): S = 2 slots x 4 waves (one per SIMD), one 122-KiB block per CU, streaming (nt) row
-  // loads + default-policy stores = 181-183 us (0.71 of the 8 TB/s roofline); nt stores 192; default loads 198;
+  // loads + default-policy stores = 181-183 us (0.71 of the 8 TB/s roofline; with sc0 sc1 write-through stores
+  // 168-176 us = 0.74-0.77, shipped); nt stores 192; default loads 198;
   // 3 slots x 3 waves 193-195; 1 slot x 8 waves 215; the register-tiled kernel 197-200.
 #define REC_RING_GO(N_, HD_, AP_, S_, W_, A_, P_, BPC_)                                                             \
   return launch_ring<N_, HD_, AP_, S_, W_, A_, P_>(ts, ids32, ids_stride, dense, dense_stride, (int)B, out, out_stride, \
@@ -374,16 +375,26 @@ bool pairdot128_ring_dispatch(const TableSet& ts, int F, bool has_dense, int ids
       case 7: REC_RING_GO(27, true, true, 2, 4, 0, 1, 1);
       case 8: REC_RING_GO(27, true, true, 2, 4, 0, 0, 1);
       case 9: REC_RING_GO(27, true, true, 2, 4, 0, 2, 1);
-      case 10: REC_RING_GO(27, true, true, 2, 4, 1, 3, 1);
-      case 20: REC_RING_GO(27, true, true, 2, 4, 2, 3, 1);
-      case 30: REC_RING_GO(27, true, true, 2, 4, 3, 3, 1);
+      case 40: REC_RING_GO(27, true, true, 2, 4, 0, 3, 1);            // stores plain (round-2 first version)
+      case 41: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 1, 1);    // stores sc0
+      case 42: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 2, 1);    // stores sc1
+      case 43: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 3, 1);    // stores sc0 sc1
+      case 44: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 4, 1);    // stores sc1 nt
+      case 45: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 5, 1);    // stores sc0 sc1 nt
+      case 51: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 3 + 32 * 1, 1);    // stores sc0 sc1, loads sc1 nt
+      case 52: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 3 + 32 * 2, 1);    // stores sc0 sc1, loads sc0 sc1 nt
+      case 53: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 3 + 32 * 3, 1);    // stores sc0 sc1, loads sc1
+      case 54: REC_RING_GO(27, true, true, 2, 4, 0, 3 + 4 * 3 + 32 * 4, 1);    // stores sc0 sc1, loads sc0 sc1
+      case 10: REC_RING_GO(27, true, true, 2, 4, 1, 15, 1);
+      case 20: REC_RING_GO(27, true, true, 2, 4, 2, 15, 1);
+      case 30: REC_RING_GO(27, true, true, 2, 4, 3, 15, 1);
       default: break;
     }
   }
 #endif
-  if (n == 27 && has_dense && append_dense) REC_RING_GO(27, true, true, 2, 4, 0, 3, 1);
-  if (n == 27 && has_dense && !append_dense) REC_RING_GO(27, true, false, 2, 4, 0, 3, 1);
-  if (n == 26 && !has_dense) REC_RING_GO(26, false, false, 2, 4, 0, 3, 1);
+  if (n == 27 && has_dense && append_dense) REC_RING_GO(27, true, true, 2, 4, 0, 15, 1);
+  if (n == 27 && has_dense && !append_dense) REC_RING_GO(27, true, false, 2, 4, 0, 15, 1);
+  if (n == 26 && !has_dense) REC_RING_GO(26, false, false, 2, 4, 0, 15, 1);
 #undef REC_RING_GO
   return false;
 }
