@@ -213,7 +213,7 @@ def wl_din(torch, dev, a, rank, world):
     # exactly 0 and are not fetched), q in, pooled row out
     need = B * (T * 3 * 4 + 2 * d * 4) + (real_slots / NB) * d * 4
     return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "kernel": "rec::din_pool_gather_kernel (fused history lookup + attention pooling)", "pmc_key": None,
+            "kernel": "rec::din_gather_pool_grp_kernel<0, 3> (fused history lookup + attention pooling, one 16-lane group per slot)", "pmc_key": None,
             "workload": "DIN var-len user history (max 100) attention pooling, batch 8192 (BASELINE configs[3])",
             "config": {"batch_per_gpu": B, "global_batch": B * world, "maxlen": T, "d": d, "vocab_per_table": V,
                        "mean_real_slots": round(real_slots / NB / B, 2),

@@ -382,6 +382,171 @@ __global__ __launch_bounds__(256) void din_gather_pool_lds_kernel(const float* _
   if (on) reinterpret_cast<f32x4*>(out + b * d)[lane] = acc * (1.f / l);
 }
 
+// Same op, one 16-lane group per history slot (round 2, second pass).  The kernel above spends ~70 VALU instructions per
+// slot: every slot is a 64-lane reduction (six cross-lane steps, two of them across DPP rows) plus two full expf and a
+// rescale of the accumulator, for 768 B of row data — rocprofv3 put it at 102.8 us for config 4 (0.41 of the HBM
+// roofline on the bytes it needs), about half of that VALU issue.  Here table rows are Dt = 64 floats = 16 lanes x 16 B,
+// so lane group g of the wave takes slot 4i + g and every lane loads its 16-B piece of EACH of the slot's n_tab rows
+// (one load instruction per table covers four slots: 1 KiB); a score is a 16-lane reduction (four DPP steps inside one
+// row), the four groups keep independent online-softmax states that are merged once at the end, the rescale happens once
+// per batch (batch maximum first), and exp is v_exp_f32 on log2(e)-scaled scores: ~14 VALU per slot.
+template <int IDS_F32, int NTAB>
+__global__ __launch_bounds__(256) void din_gather_pool_grp_kernel(const float* __restrict__ q, DinTables tb,
+                                                                  const void* __restrict__ ids,
+                                                                  const float* __restrict__ mask, int mask_mode,
+                                                                  const float* __restrict__ W,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ alpha, int act, int64_t B,
+                                                                  int T, float* __restrict__ out, int* __restrict__ oob) {
+  constexpr int Dt = 64, d = NTAB * Dt, U = 2;
+  constexpr float kLog2e = 1.4426950408889634f;
+  extern __shared__ int32_t din_lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  if (b >= B) return;
+  int32_t* sid = din_lds + (size_t)w * T * (NTAB + 1);   // [T][NTAB] ids of the sample
+  int32_t* slots = sid + (size_t)T * NTAB;                // [<= T] slots to fetch, in order; bit 31 = padded slot
+  const int sub = lane & 15, grp = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t idbase = b * (int64_t)T * NTAB;
+  const int nid = T * NTAB;
+  bool bad = false;
+  for (int e = lane; e < nid; e += 64) {
+    const int32_t id = load_id<IDS_F32>(ids, idbase + e);
+    sid[e] = id;
+    bad = bad || (uint32_t)id >= (uint32_t)tb.vocab[e % NTAB];
+  }
+  if (oob && bad) *oob = 1;
+  // score(k) = k . (w2 - w3 + q o w4) + q . (w1 + w3) + bias   (affine in the history row k)
+  f32x4 u[NTAB];
+  float cpart = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < NTAB; ++tt) {
+    const int c = tt * Dt + sub * 4;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + b * d + c);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(W + c), w2 = *reinterpret_cast<const f32x4*>(W + d + c);
+    const f32x4 w3 = *reinterpret_cast<const f32x4*>(W + 2 * d + c), w4 = *reinterpret_cast<const f32x4*>(W + 3 * d + c);
+    u[tt] = w2 - w3 + qv * w4;
+    const f32x4 cw = qv * (w1 + w3);
+    cpart += (cw.x + cw.y) + (cw.z + cw.w);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) cpart += __shfl_xor(cpart, o, 64);   // every group holds all 16 x NTAB pieces
+  const float c0 = cpart + bias[0];
+  const float al = alpha ? alpha[0] : 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto is_pad = [&](int t) -> bool {
+    if (mask_mode == 0) return true;
+    if (mask_mode == 1) return mask[b * T + t] == 0.f;
+    return sid[t * NTAB] == 0;
+  };
+  bool any_real = false;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    any_real = any_real || __any(t < T && !is_pad(t));
+  }
+  int n = 0;  // wave-uniform count of listed slots (>= 1: if no slot is real, all T are listed)
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    const bool padl = t < T ? is_pad(t) : true;
+    const bool take = t < T && (!padl || !any_real);
+    const uint64_t m = __ballot(take);
+    if (take) slots[n + __popcll(m & ((1ull << lane) - 1ull))] = t | (padl ? (int)0x80000000 : 0);
+    n += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // batch = U steps of 4 slots; slot index of (step e, group g) = i0 + 4 e + g; indices past the end re-read the last
+  // listed slot (a cache hit) and enter the softmax with the logit -inf
+  auto load_batch = [&](int i0, f32x4 (&kr)[U][NTAB]) {
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const int i = i0 + 4 * e + grp;
+      const int t = slots[i < n ? i : n - 1] & 0x7fffffff;
+#pragma unroll
+      for (int tt = 0; tt < NTAB; ++tt) {
+        const int32_t id = sid[t * NTAB + tt];
+        const bool ok = (uint32_t)id < (uint32_t)tb.vocab[tt];
+        const f32x4 row = *reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4);
+        kr[e][tt] = ok ? row : z4;
+      }
+    }
+  };
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[NTAB];
+#pragma unroll
+  for (int tt = 0; tt < NTAB; ++tt) acc[tt] = z4;
+  auto reduce_batch = [&](int i0, const f32x4 (&kr)[U][NTAB]) {
+    float s[U];
+    float mb = m;
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const int i = i0 + 4 * e + grp;
+      float dsum = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < NTAB; ++tt) {
+        const f32x4 pr = kr[e][tt] * u[tt];
+        dsum += (pr.x + pr.y) + (pr.z + pr.w);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
+      float sv = act_apply(dsum + c0, act, al);
+      if (slots[i < n ? i : n - 1] < 0) sv = kNegPad;
+      s[e] = i < n ? sv * kLog2e : -INFINITY;
+      mb = fmaxf(mb, s[e]);
+    }
+    const float mbs = mb == -INFINITY ? 0.f : mb;      // a lane group without a slot yet: all weights 0
+    const float sc = __builtin_amdgcn_exp2f(m - mbs);   // m = -inf -> 0
+    l *= sc;
+#pragma unroll
+    for (int tt = 0; tt < NTAB; ++tt) acc[tt] *= sc;
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const float p = __builtin_amdgcn_exp2f(s[e] - mbs);
+      l += p;
+#pragma unroll
+      for (int tt = 0; tt < NTAB; ++tt) acc[tt] += kr[e][tt] * p;
+    }
+    m = mb;
+  };
+  f32x4 ka[U][NTAB], kb[U][NTAB];
+  load_batch(0, ka);
+  for (int i0 = 0; i0 < n; i0 += 8 * U) {
+    load_batch(i0 + 4 * U, kb);
+    reduce_batch(i0, ka);
+    load_batch(i0 + 8 * U, ka);
+    if (i0 + 4 * U < n) reduce_batch(i0 + 4 * U, kb);
+  }
+  // merge the four group states
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, m2);
+    const float s1 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float s2 = m2 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+#pragma unroll
+    for (int tt = 0; tt < NTAB; ++tt) {
+      f32x4 a2;
+      a2.x = __shfl_xor(acc[tt].x, o, 64);
+      a2.y = __shfl_xor(acc[tt].y, o, 64);
+      a2.z = __shfl_xor(acc[tt].z, o, 64);
+      a2.w = __shfl_xor(acc[tt].w, o, 64);
+      acc[tt] = acc[tt] * s1 + a2 * s2;
+    }
+    l = l * s1 + l2 * s2;
+    m = mn;
+  }
+  if (grp == 0) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int tt = 0; tt < NTAB; ++tt) *reinterpret_cast<f32x4*>(out + b * d + tt * Dt + sub * 4) = acc[tt] * inv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K8 — match attention.  One workgroup per (sample, head, 256-query tile); the head's K and V
 // (Sk x dk each) are staged in LDS once per workgroup and read by broadcast (every thread reads
@@ -607,6 +772,31 @@ extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc
     return !(e && e[0] == 's');
   }();
   const size_t lds = (size_t)4 * T * (n_tab + 1) * sizeof(int32_t);
+  // 64-wide tables (16 lanes x 16 B per row): one lane group per history slot (din_gather_pool_grp_kernel);
+  // REC_DIN_IMPL=lds keeps the wave-per-slot kernel for A/B
+  static const bool grp_ok = [] {
+    const char* e = getenv("REC_DIN_IMPL");
+    return !(e && (e[0] == 's' || e[0] == 'l'));
+  }();
+  if (grp_ok && Dt == 64 && n_tab <= 4 && lds <= 48 * 1024) {
+#define REC_DIN_GRP(IDF_, NT_)                                                                                        \
+  hipLaunchKernelGGL((din_gather_pool_grp_kernel<IDF_, NT_>), grid, block, lds, st, q, tb, ids, mask, mode, W, bias,  \
+                     alpha, act, B, T, out, oob_flag)
+    if (ids_dtype == REC_IDS_F32) {
+      if (n_tab == 1) REC_DIN_GRP(1, 1);
+      else if (n_tab == 2) REC_DIN_GRP(1, 2);
+      else if (n_tab == 3) REC_DIN_GRP(1, 3);
+      else REC_DIN_GRP(1, 4);
+    } else {
+      if (n_tab == 1) REC_DIN_GRP(0, 1);
+      else if (n_tab == 2) REC_DIN_GRP(0, 2);
+      else if (n_tab == 3) REC_DIN_GRP(0, 3);
+      else REC_DIN_GRP(0, 4);
+    }
+#undef REC_DIN_GRP
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
   if (lds_ok && lds <= 48 * 1024) {
     if (ids_dtype == REC_IDS_F32)
       hipLaunchKernelGGL((din_gather_pool_lds_kernel<1, 4>), grid, block, lds, st, q, tb, n_tab, Dt, ids, mask, mode, W,
