@@ -179,8 +179,8 @@ def wl_autoint(torch, dev, a, rank, world):
 
     return {"step": step, "units": B, "work": B * flop, "dtype": "f32",
             "bound": "mfma", "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "kernel": "rec::mha_ctr_stack_kernel<3, 1, 2, relu> (3 interacting layers in one launch, fp32 MFMA) + gather + "
-                      "dense-field embedding + final Dense/sigmoid: whole forward", "pmc_key": None,
+            "kernel": "rec::mha_ctr_stack_kernel<3, 1, 2, relu, fused io> (rec_autoint_forward_f32: lookup + dense-field "
+                      "embedding + 3 interacting layers on fp32 MFMA + Dense(1) + sigmoid in ONE launch)", "pmc_key": None,
             "workload": "AutoInt 39 fields dim 16, 3-layer 2-head self-attn, batch 4096 (BASELINE configs[2])",
             "config": {"batch_per_gpu": B, "global_batch": B * world, "fields": F + nd, "dim": D, "layers": 3, "heads": 2,
                        "flop_per_sample": flop, "peak_note": "157.3 TFLOP/s dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"},

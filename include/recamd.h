@@ -187,6 +187,18 @@ int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv, int64_t B
 int rec_mha_ctr_stack_f32(const float* x, int64_t B, int32_t N, int32_t din, const float* const* Wq,
                           const float* const* Wk, const float* const* Wv, const float* const* W0, int32_t L, int32_t H,
                           int32_t S, int32_t act, float* out, void* stream);
+/* AutoInt.call in ONE launch (src/ctr/autoint/model.py:46-55, the `intended` 3-D form): fields of a sample =
+ * [n_sparse embedding rows fetched by id (:46) | n_dense dense values times their embedding rows (:47-50)], all D wide;
+ * the L interacting layers (rec_mha_ctr_stack_f32) run on them in registers and the flattened (N * H * S) result meets
+ * head_w / head_b (the final Dense(1), :54) and the sigmoid (:55): out_prob (B).  Neither the (B, N, D) field tensor nor
+ * the (B, N, H*S) interaction output is written unless out_fields != NULL (then it receives the latter).  Out-of-range
+ * ids read as zero rows and raise *oob_flag.  Coverage as rec_mha_ctr_stack_f32 (S = 16, D in {16, 32}, H in {1, 2},
+ * N <= 64, L <= 4); otherwise REC_ENOTIMPL. */
+int rec_autoint_forward_f32(const rec_table_desc* tables, int32_t n_sparse, const int32_t* ids, int64_t ids_stride,
+                            const float* dense, int64_t dense_stride, int32_t n_dense, const float* dense_embed, int32_t D,
+                            const float* const* Wq, const float* const* Wk, const float* const* Wv, const float* const* W0,
+                            int32_t L, int32_t H, int32_t S, int32_t act, const float* head_w, const float* head_b, int64_t B,
+                            float* out_prob, float* out_fields, int32_t* oob_flag, void* stream);
 
 /* ---- a9 / K7: DIN AttentionLayer pooling, src/ctr/layers/modules.py:144-175 ----------------
  * score[b,t] = act([q, k_t, q-k_t, q*k_t] . W + bias)  (Dense(hidden_unit=1)),

@@ -5,6 +5,7 @@
 //   K8  rec_mha_rowmask_f32    match scaled-dot-product attention src/match/layers/modules.py:76-96,115-131
 #include <stdlib.h>
 
+#include "attention_ctr.h"
 #include "common.h"
 
 namespace rec {
@@ -638,17 +639,6 @@ bool mha_ctr_b3_dispatch(const float* xq, const float* xk, const float* xv, int6
 
 using namespace rec;
 
-namespace rec {
-struct CtrStackArgs {
-  const float* Wq[4];
-  const float* Wk[4];
-  const float* Wv[4];
-  const float* W0[4];
-};
-bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const CtrStackArgs& wa, int L, int H, int S, int act,
-                            float* out, hipStream_t st);
-}  // namespace rec
-
 extern "C" int rec_mha_ctr_stack_f32(const float* x, int64_t B, int32_t N, int32_t din, const float* const* Wq,
                                      const float* const* Wk, const float* const* Wv, const float* const* W0, int32_t L,
                                      int32_t H, int32_t S, int32_t act, float* out, void* stream) {
@@ -664,9 +654,51 @@ extern "C" int rec_mha_ctr_stack_f32(const float* x, int64_t B, int32_t N, int32
     wa.Wq[l] = Wq[l], wa.Wk[l] = Wk[l], wa.Wv[l] = Wv[l];
     wa.W0[l] = W0 ? W0[l] : nullptr;
   }
-  if (!mha_ctr_stack_dispatch(x, B, N, din, wa, L, H, S, act, out, reinterpret_cast<hipStream_t>(stream))) {
+  if (!mha_ctr_stack_dispatch(x, B, N, din, wa, L, H, S, act, out, reinterpret_cast<hipStream_t>(stream), nullptr)) {
     set_error("%s: stack not covered (needs S = 16, din in {16, 32}, H in {1, 2}, N <= 64, aligned x / out): run the "
               "layers one by one with rec_mha_ctr_f32", who);
+    return REC_ENOTIMPL;
+  }
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
+}
+
+extern "C" int rec_autoint_forward_f32(const rec_table_desc* tables, int32_t n_sparse, const int32_t* ids,
+                                       int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t n_dense,
+                                       const float* dense_embed, int32_t D, const float* const* Wq, const float* const* Wk,
+                                       const float* const* Wv, const float* const* W0, int32_t L, int32_t H, int32_t S,
+                                       int32_t act, const float* head_w, const float* head_b, int64_t B, float* out_prob,
+                                       float* out_fields, int32_t* oob_flag, void* stream) {
+  using namespace rec;
+  const char* who = "rec_autoint_forward_f32";
+  REC_CHECK_ARG(B >= 0 && n_sparse >= 0 && n_dense >= 0 && n_sparse + n_dense >= 1 && D >= 1 && H >= 1 && S >= 1 && L >= 1,
+                REC_ESHAPE, "%s: bad shape", who);
+  REC_CHECK_ARG(n_sparse <= REC_MAX_TABLES, REC_ESHAPE, "%s: at most %d sparse fields", who, REC_MAX_TABLES);
+  REC_CHECK_ARG(act >= REC_ACT_NONE && act <= REC_ACT_TANH, REC_EINVAL, "%s: bad act %d", who, act);
+  if (B == 0) return REC_OK;
+  REC_CHECK_ARG(Wq && Wk && Wv && head_w && out_prob, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(n_sparse == 0 || (tables && ids && ids_stride >= n_sparse), REC_EINVAL, "%s: tables / ids", who);
+  REC_CHECK_ARG(n_dense == 0 || (dense && dense_embed && dense_stride >= n_dense), REC_EINVAL, "%s: dense / dense_embed", who);
+  REC_CHECK_ARG(L <= 4, REC_ENOTIMPL, "%s: at most 4 stacked layers per launch (got %d)", who, L);
+  CtrStackArgs wa{};
+  for (int l = 0; l < L; ++l) {
+    wa.Wq[l] = Wq[l], wa.Wk[l] = Wk[l], wa.Wv[l] = Wv[l];
+    wa.W0[l] = W0 ? W0[l] : nullptr;
+  }
+  CtrFusedIo io{};
+  for (int f = 0; f < n_sparse; ++f) {
+    REC_CHECK_ARG(tables[f].base && aligned16(tables[f].base) && tables[f].dim == D && tables[f].vocab >= 1 &&
+                      tables[f].vocab <= 0x7fffffffLL,
+                  REC_ESHAPE, "%s: table %d must be 16-B aligned, %d wide, with 1 <= vocab < 2^31", who, f, D);
+    io.ts.base[f] = tables[f].base, io.ts.vocab[f] = (int32_t)tables[f].vocab, io.ts.dim[f] = D, io.ts.out_col[f] = f * D;
+  }
+  io.ids = ids, io.ids_stride = ids_stride, io.n_sparse = n_sparse;
+  io.dense = dense, io.dense_stride = dense_stride, io.dense_embed = dense_embed;
+  io.head_w = head_w, io.head_b = head_b, io.head_out = out_prob, io.oob = reinterpret_cast<int*>(oob_flag);
+  if (!mha_ctr_stack_dispatch(nullptr, B, n_sparse + n_dense, D, wa, L, H, S, act, out_fields,
+                              reinterpret_cast<hipStream_t>(stream), &io)) {
+    set_error("%s: not covered (needs S = 16, D in {16, 32}, H in {1, 2}, <= 64 fields, 16-B aligned weights): compose "
+              "rec_gather_concat_f32 / rec_scale_embed_f32 / rec_mha_ctr_f32 / rec_dense_f32", who);
     return REC_ENOTIMPL;
   }
   REC_CHECK_LAUNCH(who);

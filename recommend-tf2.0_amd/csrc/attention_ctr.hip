@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "attention_ctr.h"
 #include "bf16x3.h"
 #include "common.h"
 
@@ -202,12 +203,7 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
 // a sample never leave the wave's registers between layers: one launch, weights of all layers staged in LDS once per
 // workgroup, the (B, N, 16 H) intermediates are neither written nor re-read, and the per-launch fixed costs (launch,
 // weight staging, first-touch latency of the rows: most of a 37-us layer at 4096 samples = one wave each) are paid once.
-struct CtrStackArgs {
-  const float* Wq[4];
-  const float* Wk[4];
-  const float* Wv[4];
-  const float* W0[4];
-};
+
 
 namespace cf32 {
 // VALU diet (rocprofv3 counters, round 2: the first version issued 2 169 VALU instructions per sample and layer against
@@ -314,9 +310,9 @@ __device__ __forceinline__ void stage_weights(f32x4* __restrict__ wl, const floa
 }
 }  // namespace cf32
 
-template <int NT, int KS0, int H, int ACT>
+template <int NT, int KS0, int H, int ACT, bool IO = false>
 __global__ __launch_bounds__(256) void mha_ctr_stack_kernel(const float* __restrict__ x, int64_t B, int N, CtrStackArgs wa,
-                                                            int L, int act, float* __restrict__ out) {
+                                                            int L, int act, float* __restrict__ out, CtrFusedIo io = {}) {
   using namespace cf32;
   extern __shared__ __attribute__((aligned(16))) f32x4 wstack[];
   constexpr int din0 = 16 * KS0, HS = 16 * H;
@@ -335,8 +331,24 @@ __global__ __launch_bounds__(256) void mha_ctr_stack_kernel(const float* __restr
     for (int rt = 0; rt < NT; ++rt) {
       const int n = rt * 16 + lr;
 #pragma unroll
-      for (int ks = 0; ks < KS0; ++ks)
-        x0[rt][ks] = n < N ? *reinterpret_cast<const f32x4*>(x + (b * N + n) * (int64_t)din0 + 16 * ks + 4 * g) : zero;
+      for (int ks = 0; ks < KS0; ++ks) {
+        if constexpr (IO) {
+          f32x4 v = zero;
+          if (n < io.n_sparse) {          // an embedding row, fetched by id; out-of-range ids read as zero rows
+            const int32_t id = io.ids[b * io.ids_stride + n];
+            const bool ok = (uint32_t)id < (uint32_t)io.ts.vocab[n];
+            if (!ok && io.oob) *io.oob = 1;
+            const f32x4 row = *reinterpret_cast<const f32x4*>(io.ts.base[n] + (int64_t)(ok ? id : 0) * din0 + 16 * ks + 4 * g);
+            v = ok ? row : zero;
+          } else if (n < N) {             // a dense value times its embedding row
+            const int j = n - io.n_sparse;
+            v = *reinterpret_cast<const f32x4*>(io.dense_embed + j * din0 + 16 * ks + 4 * g) * io.dense[b * io.dense_stride + j];
+          }
+          x0[rt][ks] = v;
+        } else {
+          x0[rt][ks] = n < N ? *reinterpret_cast<const f32x4*>(x + (b * N + n) * (int64_t)din0 + 16 * ks + 4 * g) : zero;
+        }
+      }
     }
     f32x4 ya[NT][H], yb[NT][H];
     ctr_layer<NT, KS0, H, ACT>(x0, wstack, wa.W0[0] != nullptr, act, N, lr, g, ya);
@@ -346,6 +358,25 @@ __global__ __launch_bounds__(256) void mha_ctr_stack_kernel(const float* __restr
       for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
         for (int h = 0; h < H; ++h) ya[rt][h] = yb[rt][h];
+    }
+    if constexpr (IO) {
+      // sigmoid(Dense(1)(flatten(out))): lane (field, g) holds out[field][16 h + 4g .. + 3]
+      float acc = 0.f;
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt) {
+        const int qi = qt * 16 + lr;
+        if (qi < N) {
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(io.head_w + qi * HS + h * 16 + 4 * g);
+            const f32x4 pr = ya[qt][h] * wv;
+            acc += (pr.x + pr.y) + (pr.z + pr.w);
+          }
+        }
+      }
+      acc = wave_sum(acc) + (io.head_b ? io.head_b[0] : 0.f);
+      if (lane == 0) io.head_out[b] = act_apply(acc, REC_ACT_SIGMOID, 0.f);
+      if (!out) continue;
     }
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
@@ -360,9 +391,10 @@ __global__ __launch_bounds__(256) void mha_ctr_stack_kernel(const float* __restr
 
 // returns false when the stack is not covered (the caller runs the layers one by one)
 bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const CtrStackArgs& wa, int L, int H, int S, int act,
-                            float* out, hipStream_t st) {
+                            float* out, hipStream_t st, const CtrFusedIo* io) {
   if (S != 16 || !(din == 16 || din == 32) || N > 64 || N < 1 || L < 1 || L > 4 || !(H == 1 || H == 2)) return false;
-  if (!aligned16(x) || !aligned16(out)) return false;
+  if (!io && (!aligned16(x) || !aligned16(out))) return false;
+  if (io && ((out && !aligned16(out)) || !aligned16(io->head_w) || !aligned16(io->dense_embed))) return false;
   for (int l = 0; l < L; ++l)
     if (!wa.Wq[l] || !wa.Wk[l] || !wa.Wv[l]) return false;
   const int NT = (N + 15) / 16, KS0 = din / 16;
@@ -380,11 +412,18 @@ bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const Ctr
   const dim3 grid((unsigned)blocks), block(256);
 #define REC_CST(NT_, KS_, H_)                                                                                       \
   do {                                                                                                              \
-    if (act == REC_ACT_RELU)                                                                                        \
+    if (io && act == REC_ACT_RELU)                                                                                  \
+      hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, REC_ACT_RELU, true>), grid, block, lds, st, x, B, N, wa, L, \
+                         act, out, *io);                                                                            \
+    else if (io)                                                                                                    \
+      hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, -1, true>), grid, block, lds, st, x, B, N, wa, L, act, out, \
+                         *io);                                                                                      \
+    else if (act == REC_ACT_RELU)                                                                                   \
       hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, REC_ACT_RELU>), grid, block, lds, st, x, B, N, wa, L, act, \
-                         out);                                                                                      \
+                         out, CtrFusedIo{});                                                                        \
     else                                                                                                            \
-      hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, -1>), grid, block, lds, st, x, B, N, wa, L, act, out); \
+      hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, -1>), grid, block, lds, st, x, B, N, wa, L, act, out,  \
+                         CtrFusedIo{});                                                                             \
   } while (0)
 #define REC_CST_NT(KS_, H_)              \
   do {                                   \
@@ -419,7 +458,7 @@ bool mha_ctr_b3_dispatch(const float* xq, const float* xk, const float* xv, int6
   if (!use_b3) {
     CtrStackArgs wa{};
     wa.Wq[0] = Wq, wa.Wk[0] = Wk, wa.Wv[0] = Wv, wa.W0[0] = W0;
-    if (mha_ctr_stack_dispatch(xq, B, N, din, wa, 1, H, S, act, out, st)) return true;
+    if (mha_ctr_stack_dispatch(xq, B, N, din, wa, 1, H, S, act, out, st, nullptr)) return true;
   }
   const size_t lds = (size_t)4 * H * 3 * 4 * 16 * sizeof(u32x4);
 #define REC_CB3(NT_)                                                                                              \

@@ -592,5 +592,26 @@ PYBIND11_MODULE(_C, m) {
     check(rec_pairwise_rank_loss_f32(P<const float>(logits), stride, B, n_neg, P<float>(out), P<void>(ws), P<void>(stream)),
           "rec_pairwise_rank_loss_f32");
   });
+  m.def("autoint_forward_f32", [](const std::vector<TableTuple>& tables, ptr_t ids, int64_t ids_stride, ptr_t dense,
+                                  int64_t dense_stride, int n_dense, ptr_t dense_embed, int D, const std::vector<ptr_t>& Wq,
+                                  const std::vector<ptr_t>& Wk, const std::vector<ptr_t>& Wv, const std::vector<ptr_t>& W0,
+                                  int H, int S, int act, ptr_t head_w, ptr_t head_b, int64_t B, ptr_t out_prob,
+                                  ptr_t out_fields, ptr_t oob, ptr_t stream) {
+    const size_t L = Wq.size();
+    if (Wk.size() != L || Wv.size() != L || (!W0.empty() && W0.size() != L))
+      throw std::runtime_error("autoint_forward_f32: weight lists must have one entry per layer");
+    auto d = to_descs(tables);
+    std::vector<const float*> q, k, v, r;
+    for (size_t l = 0; l < L; ++l) {
+      q.push_back(P<const float>(Wq[l])), k.push_back(P<const float>(Wk[l])), v.push_back(P<const float>(Wv[l]));
+      r.push_back(W0.empty() ? nullptr : P<const float>(W0[l]));
+    }
+    py::gil_scoped_release nogil;
+    check(rec_autoint_forward_f32(d.data(), (int32_t)d.size(), P<const int32_t>(ids), ids_stride, P<const float>(dense),
+                                  dense_stride, n_dense, P<const float>(dense_embed), D, q.data(), k.data(), v.data(),
+                                  r.data(), (int32_t)L, H, S, act, P<const float>(head_w), P<const float>(head_b), B,
+                                  P<float>(out_prob), P<float>(out_fields), P<int32_t>(oob), P<void>(stream)),
+          "rec_autoint_forward_f32");
+  });
 }
 

@@ -58,6 +58,30 @@ class AutoInt(Model):
             fd.build(flat.shape[-1])
         return ops.dense(flat, fd._w['kernel'], fd._w.get('bias'), 'sigmoid')
 
+    def _fused_forward(self, dense_inputs, sparse_inputs, F, D):
+        """the whole call — lookup, dense-field embedding, interacting layers, Dense(1), sigmoid — in ONE launch
+        (rec_autoint_forward_f32) when the configuration is covered; None otherwise.  REC_AUTOINT_IMPL=layers keeps
+        the separate launches."""
+        import os
+        if os.environ.get('REC_AUTOINT_IMPL') == 'layers' or sparse_inputs.dtype != torch.int32:
+            return None
+        layers = self.attention_layers
+        hs = layers[0]._head_num * layers[0]._head_size
+        same = all(L._head_num == layers[0]._head_num and L._head_size == layers[0]._head_size and
+                   L._activation == layers[0]._activation for L in layers)
+        if not same or not isinstance(layers[0]._activation, (str, type(None))):
+            return None
+        for i, L in enumerate(layers):
+            if not L.built:
+                L.build(D if i == 0 else hs)
+        fd = self.final_dense
+        if not fd.built:
+            fd.build((F + self.nd) * hs)
+        return ops.autoint_forward(self._group, sparse_inputs, dense_inputs, self._w['dense_embed'],
+                                   [(L._w['Wq'], L._w['Wk'], L._w['Wv'], L._w.get('W0')) for L in layers],
+                                   layers[0]._head_num, layers[0]._head_size, layers[0]._activation, fd._w['kernel'],
+                                   fd._w.get('bias'))
+
     def _interact(self, h):
         """the stacked interacting layers: ONE launch when the fused stack kernel covers them (activations stay in
         registers between layers), else layer by layer"""
@@ -86,6 +110,9 @@ class AutoInt(Model):
             # fields of one sample = [26 looked-up rows | 13 value-scaled dense embeddings]: the gather and the scaling
             # kernel write the two parts of ONE (B, (F + nd) * D) buffer (tf.concat as column offsets, no copy pass)
             D = self._group.dims[0]
+            fused = self._fused_forward(dense_inputs, sparse_inputs, F, D)
+            if fused is not None:
+                return fused
             buf = torch.empty((B, (F + self.nd) * D), dtype=torch.float32, device=self.device)
             ops.gather_concat(self._group, sparse_inputs, out=buf)                # :46
             ops.scale_embed(dense_inputs, self._w['dense_embed'], buf[:, F * D:])

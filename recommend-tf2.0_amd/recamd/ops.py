@@ -324,6 +324,51 @@ def mha_ctr_stack(x: torch.Tensor, layers, head_num: int, head_size: int, act="r
     return out
 
 
+def autoint_forward(group: "TableGroup", ids: torch.Tensor, dense: torch.Tensor, dense_embed: torch.Tensor, layers,
+                    head_num: int, head_size: int, act, head_w: torch.Tensor, head_b: Optional[torch.Tensor],
+                    oob_flag=None) -> Optional[torch.Tensor]:
+    """AutoInt.call (src/ctr/autoint/model.py:46-55, 3-D form) in ONE launch: fields = [embedding rows of `ids` | dense
+    values x dense_embed rows], the stacked interacting layers in registers, Dense(1) + sigmoid on the flattened result.
+    layers = [(Wq, Wk, Wv, W0|None), ...].  Returns probabilities (B, 1), or None when the fused kernel does not cover
+    the configuration (the caller composes the separate ops)."""
+    F = len(group)
+    if F > C.MAX_TABLES or len(set(group.dims)) != 1:
+        return None
+    D = group.dims[0]
+    HS = head_num * head_size
+    L = len(layers)
+    if head_size != 16 or D not in (16, 32) or head_num not in (1, 2) or not 1 <= L <= 4:
+        return None
+    if ids.dtype != torch.int32:
+        return None
+    _rows2d(_chk(ids, "ids", torch.int32), "ids")
+    _rows2d(_chk(dense, "dense"), "dense")
+    _chk(dense_embed, "dense_embed")
+    B, nd = dense.shape
+    N = F + nd
+    if ids.shape != (B, F) or tuple(dense_embed.shape) != (nd, D) or not dense_embed.is_contiguous() or N > 64:
+        return None
+    has_res = [w[3] is not None for w in layers]
+    if any(has_res) and not all(has_res):
+        return None
+    for l, (wq, wk, wv, w0) in enumerate(layers):
+        kin = D if l == 0 else HS
+        for t in (wq, wk, wv) + ((w0,) if w0 is not None else ()):
+            _chk(t, "W")
+            if tuple(t.shape) != (kin, HS) or not t.is_contiguous():
+                return None
+    head_w = _chk(head_w, "head_w").reshape(-1)
+    if head_w.numel() != N * HS or not head_w.is_contiguous():
+        return None
+    out = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
+    C.autoint_forward_f32(group.descs, ids.data_ptr(), ids.stride(0), dense.data_ptr(), dense.stride(0), nd,
+                          dense_embed.data_ptr(), D, [w[0].data_ptr() for w in layers], [w[1].data_ptr() for w in layers],
+                          [w[2].data_ptr() for w in layers], [w[3].data_ptr() for w in layers] if all(has_res) else [],
+                          head_num, head_size, _act_id(act), head_w.data_ptr(), _ptr(head_b), B, out.data_ptr(), 0,
+                          _ptr(oob_flag), _stream())
+    return out
+
+
 def din_attention_pool(q, k, v, mask, W, bias, act="sigmoid", alpha=None) -> torch.Tensor:
     """DIN AttentionLayer (src/ctr/layers/modules.py:144-175), hidden_unit = 1.
     q (B,d); k,v (B,T,d); mask (B,T) float tensor or None (None => uniform, modules.py:164-165)."""

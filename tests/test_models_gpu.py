@@ -127,6 +127,47 @@ def test_autoint_intended_config3_shape(dev):
     assert close(out, exp)
 
 
+@pytest.mark.parametrize("B,nd,F,heads,L,res", [(96, 13, 26, 2, 3, True), (5, 1, 7, 1, 1, False), (130, 3, 40, 2, 2, True),
+                                                (33, 64 - 17, 17, 1, 4, False)])
+def test_autoint_one_launch_forward(dev, monkeypatch, B, nd, F, heads, L, res):
+    """rec_autoint_forward_f32 (lookup + dense-field embedding + interacting layers + Dense(1) + sigmoid in one launch)
+    against the oracle, and the mirror's two paths against each other; out-of-range ids read as zero rows + flag."""
+    from ctr.autoint.model import AutoInt
+    from recamd import ops
+    rng = np.random.default_rng(B + nd)
+    vocabs = [int(v) for v in rng.integers(3, 300, size=F)]
+    cols = [dense_cols(nd), sparse_cols(vocabs, 16)]
+    m = AutoInt(cols, att_hidden_units=16, head_num=heads, att_layer_num=L, use_res=res)
+    dense, ids = inputs(rng, B, vocabs, nd)
+    m([dense, ids])
+    w = randomize(m, rng, 0.2)
+    out = m([dense, ids]).cpu().numpy()
+    monkeypatch.setenv("REC_AUTOINT_IMPL", "layers")
+    out_layers = m([dense, ids]).cpu().numpy()
+    monkeypatch.delenv("REC_AUTOINT_IMPL")
+    tables = [w[f'embed_{i}/embeddings'] for i in range(F)]
+    emb = ref.gather_concat([t.astype(np.float64) for t in tables], ids).reshape(B, F, 16)
+    x3 = emb if nd == 0 else np.concatenate(
+        [emb, dense[:, :, None].astype(np.float64) * w['dense_embed'][None].astype(np.float64)], axis=1)
+    layers = [dict(Wq=w[f'attention_{i}/Wq'], Wk=w[f'attention_{i}/Wk'], Wv=w[f'attention_{i}/Wv'],
+                   W0=w.get(f'attention_{i}/W0')) for i in range(L)]
+    exp = ref.autoint_forward_intended(x3, layers, (w['final_dense/kernel'], w['final_dense/bias']), heads, 16, 'relu', res)
+    assert close(out, exp) and close(out_layers, exp)
+    # the op itself, with an out-of-range id
+    ids2 = ids.copy()
+    ids2[B // 2, F - 1] = vocabs[F - 1] + 3
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    t_ids, t_dense = torch.from_numpy(ids2.astype(np.int32)).to(dev), torch.from_numpy(dense.astype(np.float32)).to(dev)
+    got = ops.autoint_forward(m._group, t_ids, t_dense, m._w['dense_embed'],
+                              [(A._w['Wq'], A._w['Wk'], A._w['Wv'], A._w.get('W0')) for A in m.attention_layers], heads, 16,
+                              'relu', m.final_dense._w['kernel'], m.final_dense._w.get('bias'), oob_flag=flag)
+    assert got is not None and int(flag.item()) == 1
+    emb2 = ref.gather_concat([t.astype(np.float64) for t in tables], ids2).reshape(B, F, 16)
+    x3b = emb2 if nd == 0 else np.concatenate([emb2, x3[:, F:]], axis=1)
+    exp2 = ref.autoint_forward_intended(x3b, layers, (w['final_dense/kernel'], w['final_dense/bias']), heads, 16, 'relu', res)
+    assert close(got.cpu().numpy(), exp2)
+
+
 def test_autoint_as_written_sample_mixing(dev):
     """The reference's 2-D call (autoint/model.py:48-51): output batch is B / att_hidden_units."""
     from ctr.autoint.model import AutoInt
