@@ -15,6 +15,8 @@
 // compute phase is 12 conflict-free ds_read_b128 per 24 MFMAs.  LDS is double-buffered, one barrier per k-step.
 // Epilogue: bias + activation, then each wave transposes its 64 x 64 tile through LDS so that it leaves as 16-B
 // row-major stores (65 536 x 13 x 512, an output-bound layer: 0.046 -> 0.033 ms).
+#include <stdlib.h>
+
 #include "bf16x3.h"
 #include "common.h"
 
@@ -27,6 +29,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace b3 {
 constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef REC_DENSE_PD
+#define REC_DENSE_PD 2
+#endif
+// global loads run PD k-steps ahead of the MFMAs that consume them, in PD register sets (a k-step is ~0.35 us of matrix
+// work per wave, an L2 / HBM round trip 0.6 - 2 us: one step ahead leaves the wave waiting at the LDS write)
+constexpr int PD = REC_DENSE_PD;
 
 using bf16x3::split8;
 }  // namespace b3
@@ -88,9 +96,9 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float av[8], bv[8];
-  u32x4 bq[3];
-  auto gload = [&](int k0) {
+  float avs[PD][8], bvs[BPREP ? 1 : PD][8];
+  u32x4 bqs[BPREP ? PD : 1][3];
+  auto gload = [&](int k0, float (&av)[8], float (&bv)[8], u32x4 (&bq)[3]) {
     const int kb = k0 + 8 * skh;
     if constexpr (x_vec == 2) {
       const int kk = tid & 15, r0 = tid >> 4;
@@ -108,10 +116,9 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? xrow[kb + j] : 0.f;
     }
-    if (x_vec != 2 && !m_ok) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) av[j] = 0.f;
-    }
+    // rows >= M read row 0 (xrow) and are NOT zeroed: an A row only feeds its own C row, which the epilogue never
+    // stores — and a select on the loaded values here would make every gload wait for its own loads (it did: the
+    // compiler placed s_waitcnt vmcnt(3) right behind the W loads, exposing one x round trip per k-step)
     if constexpr (BPREP) {
       // prepared weights: [k / 8][plane][Np] fragments, already split (rec_dense_prepare_f32); padded with zeros
       const int64_t k8 = (k0 >> 3) + skh;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
       for (int j = 0; j < 8; ++j) bv[j] = (n_ok && kb + j < K) ? W[(int64_t)(kb + j) * N + gn] : 0.f;
     }
   };
-  auto lwrite = [&](int st) {
+  auto lwrite = [&](int st, float (&av)[8], float (&bv)[8], u32x4 (&bq)[3]) {
     u32x4 h, m, l;
     if constexpr (x_vec == 2) {
       float(*xs)[17] = reinterpret_cast<float(*)[17]>(&frag[st][1][0][0][0]);  // 128 x 17 floats < 12 KiB
@@ -151,12 +158,14 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
   };
 
   const int nk = (K + BK - 1) / BK;
-  gload(0);
-  lwrite(0);
+#define REC_SET_(s) avs[s], bvs[BPREP ? 0 : (s)], bqs[BPREP ? (s) : 0]
+  // prologue: k-steps 0 .. PD-1 leave; step 0 goes to LDS
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s < nk) gload(s * BK, REC_SET_(s));
+  lwrite(0, REC_SET_(0));
   __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int st = ks & 1;
-    if (ks + 1 < nk) gload((ks + 1) * BK);
+  auto compute = [&](int st) {
     bf16x8 a[2][3], b[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -178,9 +187,22 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // m m
         acc[i][j] = c;
       }
-    if (ks + 1 < nk) lwrite(st ^ 1);
-    __syncthreads();
+  };
+  // iteration ks: set ks % PD (step ks, already in LDS) is refilled with step ks + PD; the MFMAs of step ks run; step
+  // ks + 1 (loaded PD - 1 iterations ago into set (ks + 1) % PD) is split and written to the other LDS stage
+  for (int ks0 = 0; ks0 < nk; ks0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int ks = ks0 + u;
+      if (ks >= nk) break;
+      const int st = ks & 1;
+      if (ks + PD < nk) gload((ks + PD) * BK, REC_SET_(u));
+      compute(st);
+      if (ks + 1 < nk) lwrite(st ^ 1, REC_SET_((u + 1) % PD));
+      __syncthreads();
+    }
   }
+#undef REC_SET_
 
   // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
   if (out_vec) {
@@ -231,6 +253,198 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
     }
 }
 
+// ---- the same tile with hand-counted global loads (aligned x rows, prepared W, K % 32 == 0) -----------------------
+// In the kernel above the compiler owns the s_waitcnt placement, and across the loop's control flow it gives up on the
+// issue order: the ISA has `s_waitcnt vmcnt(2) / (1) / (0)` in front of the LDS writes of the PREVIOUS step's W planes —
+// it also waits for the loads it has just issued for the next step, so every k-step pays a full L2 / HBM round trip
+// (0.6 - 2 us against 0.35 us of matrix work per step; measured: prefetch distances 1, 2, 3, 4 all within 7 %).  With a
+// straight-line body and plain loads it derives exact counts but sinks the loads next to their uses.  So the loop's
+// loads are inline asm in a fixed order — per thread and k-step [x lo][x hi][W h][W m][W l] — and the counts are static:
+// at the LDS write of step ks + 1 the five loads of step ks + 2 may all be in flight (vmcnt(8) for its x pieces: three
+// older W loads + five newer; vmcnt(5) for its W planes).  Two register sets, loop unrolled by two, the last pair
+// peeled (no loads, vmcnt(3) / (0)): nothing is in flight at the epilogue.
+// The wait asm returns a zero the consumers fold in (xor into the x values, add to the LDS index of the W planes): the
+// data dependency that keeps their instructions below the wait.  (A tied 128-bit "+v" operand would be the natural way;
+// this toolchain lowers it as if the four elements were equal — the first version split one value per 16-B piece.)
+__device__ __forceinline__ void gl16(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+#define REC_DWAIT_X(n, tok, a, b) \
+  asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b) : "memory")
+#define REC_DWAIT_W(n, tok, a, b, c) \
+  asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b), "v"(c) : "memory")
+
+__global__ __launch_bounds__(256, 2) void dense_bf16x3_pipe_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ alpha, int act, int64_t M,
+                                                                   int K, int N, float* __restrict__ out,
+                                                                   int64_t out_stride, int out_vec,
+                                                                   const u32x4* __restrict__ Wp, int Np, int xcd_map) {
+  using namespace b3;
+  __shared__ u32x4 frag[2][2][3][2][128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int ntn = (N + BN - 1) / BN;
+  const int64_t ntm = (M + BM - 1) / BM;
+  const int64_t L = blockIdx.x;
+  int64_t mt;
+  int nt_;
+  if (xcd_map) {
+    const int xcd = (int)(L & 7);
+    const int64_t slot = L >> 3;
+    mt = (slot / ntn) * 8 + xcd;
+    nt_ = (int)(slot % ntn);
+  } else {
+    mt = L % ntm;
+    nt_ = (int)(L / ntm);
+  }
+  if (mt >= ntm || nt_ >= ntn) return;
+  const int64_t m0 = mt * BM;
+  const int n0 = nt_ * BN;
+  const int srow = tid & 127, skh = tid >> 7;
+  const int64_t gm = m0 + srow;
+  const float* xrow = x + (gm < M ? gm : 0) * x_stride + 8 * skh;        // rows >= M read row 0; never stored
+  const u32x4* wcol = Wp + (int64_t)skh * 3 * Np + n0 + srow;            // + (ks * 2) * 3 * Np per k-step
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  u32x4 xa[2][2], wq[2][3];
+  auto issue = [&](int ks, u32x4 (&xs)[2], u32x4 (&ws)[3]) {
+    const float* px = xrow + ks * BK;
+    const u32x4* pw = wcol + (int64_t)ks * 6 * Np;
+    gl16(xs[0], px);
+    gl16(xs[1], px + 4);
+    gl16(ws[0], pw);
+    gl16(ws[1], pw + Np);
+    gl16(ws[2], pw + 2 * Np);
+  };
+  auto lwrite_x = [&](int st, const u32x4 (&xs)[2], uint32_t tok) {
+    float av[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      av[j] = __builtin_bit_cast(float, xs[0][j] ^ tok), av[4 + j] = __builtin_bit_cast(float, xs[1][j] ^ tok);
+    u32x4 h, m, l;
+    split8(av, h, m, l);
+    frag[st][0][0][skh][srow] = h;
+    frag[st][0][1][skh][srow] = m;
+    frag[st][0][2][skh][srow] = l;
+  };
+  auto lwrite_w = [&](int st, const u32x4 (&ws)[3], uint32_t tok) {
+    frag[st][1][0][skh][srow + tok] = ws[0];
+    frag[st][1][1][skh][srow + tok] = ws[1];
+    frag[st][1][2][skh][srow + tok] = ws[2];
+  };
+  auto compute = [&](int st) {
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[t][p] = __builtin_bit_cast(bf16x8, frag[st][0][p][half][wm * 64 + t * 32 + l32]);
+        b[t][p] = __builtin_bit_cast(bf16x8, frag[st][1][p][half][wn * 64 + t * 32 + l32]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // h h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);  // h m
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);  // m h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);  // h l
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);  // l h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // m m
+        acc[i][j] = c;
+      }
+  };
+  const int nk = K / BK;   // even, >= 2
+  uint32_t tok;
+#define REC_STEP_WRITE(n_x, n_w, st, S)              \
+  REC_DWAIT_X(n_x, tok, xa[S][0], xa[S][1]);         \
+  lwrite_x(st, xa[S], tok);                          \
+  REC_DWAIT_W(n_w, tok, wq[S][0], wq[S][1], wq[S][2]); \
+  lwrite_w(st, wq[S], tok)
+  issue(0, xa[0], wq[0]);
+  issue(1, xa[1], wq[1]);
+  REC_STEP_WRITE(8, 5, 0, 0);
+  __syncthreads();
+  for (int ks = 0; ks + 2 < nk; ks += 2) {
+    // step ks (stage 0, set 0 free again): refill set 0 with step ks + 2, write step ks + 1 from set 1 to stage 1
+    issue(ks + 2, xa[0], wq[0]);
+    compute(0);
+    REC_STEP_WRITE(8, 5, 1, 1);
+    __syncthreads();
+    // step ks + 1 (stage 1): refill set 1 with step ks + 3, write step ks + 2 from set 0 to stage 0
+    issue(ks + 3, xa[1], wq[1]);
+    compute(1);
+    REC_STEP_WRITE(8, 5, 0, 0);
+    __syncthreads();
+  }
+  // last pair: nothing left to load
+  compute(0);
+  REC_STEP_WRITE(3, 0, 1, 1);
+  __syncthreads();
+  compute(1);
+  __syncthreads();
+#undef REC_STEP_WRITE
+
+  // epilogue (as above): C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+  if (out_vec) {
+    constexpr int LDO = 64 + 4;
+    float* ot = reinterpret_cast<float*>(&frag[0][0][0][0][0]) + wv * 32 * LDO;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l32;
+        const float bb = (bias && col < N) ? bias[col] : 0.f;
+        const float al = (alpha && col < N) ? alpha[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ot[((r & 3) + 8 * (r >> 2) + 4 * half) * LDO + j * 32 + l32] = act_apply(acc[i][j][r] + bb, act, al);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = e * 64 + lane, rr = idx >> 4, c4 = idx & 15;
+        const int64_t row = m0 + wm * 64 + i * 32 + rr;
+        const int col = n0 + wn * 64 + 4 * c4;
+        if (row < M && col < N)
+          *reinterpret_cast<f32x4*>(out + row * out_stride + col) = *reinterpret_cast<const f32x4*>(ot + rr * LDO + 4 * c4);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l32;
+      if (col >= N) continue;
+      const float bb = bias ? bias[col] : 0.f;
+      const float al = alpha ? alpha[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][r] + bb, act, al);
+      }
+    }
+}
+
+#undef REC_DWAIT_X
+#undef REC_DWAIT_W
+
 // W -> [ceil(K/16)*2][3 planes][Np = round_up(N, 128)] bf16x8 fragments (8 consecutive k of one column each)
 __global__ __launch_bounds__(256) void dense_prepare_kernel(const float* __restrict__ W, int K, int N, int Np, int K8,
                                                             u32x4* __restrict__ Wp) {
@@ -271,6 +485,13 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
 #define REC_B3_GO(XM_, BP_)                                                                                      \
   hipLaunchKernelGGL((dense_bf16x3_kernel<XM_, BP_>), grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, \
                      N, out, out_stride, out_vec, wp, Np, xcd_map)
+  // aligned x rows + prepared W + K a multiple of 32: the hand-counted pipeline (REC_DENSE_PIPE=0 reads once: A/B)
+  static const bool pipe_ok = [] { const char* e = getenv("REC_DENSE_PIPE"); return !(e && e[0] == '0'); }();
+  if (pipe_ok && wp && x_vec == 1 && K % 32 == 0 && K >= 32) {
+    hipLaunchKernelGGL(dense_bf16x3_pipe_kernel, grid, dim3(256), 0, st, x, x_stride, bias, alpha, act, M, K, N, out,
+                       out_stride, out_vec, wp, Np, xcd_map);
+    return true;
+  }
   if (wp && x_vec != 2) {  // with the transpose-tile x path the prepared form measured slower (1.10 vs 0.88 ms at K = 3341)
     if (x_vec == 1) REC_B3_GO(1, true);
     else REC_B3_GO(0, true);
