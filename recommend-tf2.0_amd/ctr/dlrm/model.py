@@ -25,6 +25,7 @@ class DLRM(Model):
         if interaction not in ('cat', 'dot'):
             raise ValueError("interaction must be 'cat' or 'dot'")
         self.interaction = interaction
+        self._dot_buf = None
         self.embed_reg = embed_reg
         self.dense_feature_columns, self.sparse_feature_columns = feature_columns
         self.embed_layers = {
@@ -47,9 +48,22 @@ class DLRM(Model):
         dense_inputs = to_device_f32(dense_inputs, self.device)
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
         B = sparse_inputs.shape[0]
+        tail_pad = 0
         if self.interaction == 'dot':
             dense_fea = self.bot_dnn(dense_inputs)                             # intended :44
-            x = ops.gather_pairwise_dot(self._group, sparse_inputs, dense_fea, append_dense=True)
+            # the (B, P + Hb) result lives in a buffer whose row stride is rounded up to 4 floats; the buffer is kept
+            # (zero-initialised once, the kernels never write anything but zeros into its pad columns), so the top MLP
+            # can read the padded width with a zero weight row appended: its first GEMM then has aligned rows and, for
+            # the DLRM shape (351 + 128 = 479 -> 480), K a multiple of 32
+            F = len(self._group)
+            width = (F + 1) * F // 2 + dense_fea.shape[1]
+            wide = (width + 3) // 4 * 4
+            if self._dot_buf is None or self._dot_buf.shape != (B, wide):
+                self._dot_buf = torch.zeros((B, wide), dtype=torch.float32, device=self.device)
+            x = ops.gather_pairwise_dot(self._group, sparse_inputs, dense_fea, append_dense=True,
+                                        out=self._dot_buf[:, :width])
+            if wide != width and x.data_ptr() == self._dot_buf.data_ptr():
+                x, tail_pad = self._dot_buf, wide - width
         else:
             # tf.concat([sparse_embed, dense_fea]) (:48) without a copy: the gather writes the sparse part of one
             # (B, sum D + bot) buffer and the bottom MLP's last layer writes its tail (16-B aligned tail: directly;
@@ -63,5 +77,5 @@ class DLRM(Model):
             else:
                 ops.copy_cols(self.bot_dnn(dense_inputs), buf[:, W:])
             x = buf[:, :W + Hb]
-        top = self.final_dense(self.top_dnn(x))                                # intended :50-51
+        top = self.final_dense(self.top_dnn(x, tail_pad=tail_pad))             # intended :50-51
         return ops.add_sigmoid(top)                                            # :53
