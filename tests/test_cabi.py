@@ -69,6 +69,42 @@ def test_shape_validation_without_gpu(lib):
     assert lib.rec_fm_layer_workspace_floats(ctypes.c_int64(65536)) >= 4096
 
 
+def test_header_is_c99_and_a_c_consumer_links(tmp_path):
+    """include/recamd.h is the boundary a C / cgo / JNI consumer binds: it must compile as plain C99 and link against
+    librecamd.so without torch or python in the process (argument validation runs without a GPU)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "consumer.c"
+    src.write_text("""
+#include <stdio.h>
+#include <string.h>
+#include "recamd.h"
+int main(void) {
+  char buf[256];
+  rec_table_desc d = {0};
+  rec_sasrec_block blk;
+  memset(&blk, 0, sizeof blk);
+  if (rec_version() != 100) return 1;
+  if (rec_gather_concat_f32(NULL, 3, NULL, REC_IDS_I32, 3, 1, NULL, 4, NULL, NULL) != REC_EINVAL) return 2;
+  if (rec_last_error(buf, sizeof buf) <= 0 || !strstr(buf, "NULL")) return 3;
+  if (rec_sasrec_last_row_supported(64, 128, 200, 101) != 1 || rec_sasrec_last_row_supported(48, 128, 200, 101) != 0) return 4;
+  if (rec_sasrec_last_row_f32(&blk, NULL, 1, NULL, 0, 1, 0, NULL, 0, NULL, 0, NULL, 0, 0, NULL, 0, NULL, 0, 0, 1, 64, NULL,
+                              NULL, 0, NULL, NULL) != REC_EINVAL) return 5;
+  (void)d;
+  puts("ok");
+  return 0;
+}
+""")
+    exe = tmp_path / "consumer"
+    libdir = os.path.dirname(LIB)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir,
+                           "-lrecamd", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
+
+
 def test_pybind_shim_imports_and_wraps_everything():
     import recamd
     c_names = {n[4:] for n in declared_functions() if n not in ("rec_version", "rec_last_error")}
