@@ -323,7 +323,11 @@ def to_device_ids(x, device) -> torch.Tensor:
     the kernel)."""
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(np.ascontiguousarray(x))
-    if x.dtype in (torch.int64, torch.int16, torch.int8, torch.uint8):
+    if x.dtype == torch.int64:
+        # ids outside int32 must stay out of range after the narrowing (a wrapped 2**32 + 5 would alias row 5): they
+        # saturate to -1 / INT32_MAX, which no table holds, so the kernels report them like any other bad id
+        x = x.clamp(-1, 2 ** 31 - 1).to(torch.int32)
+    elif x.dtype in (torch.int16, torch.int8, torch.uint8):
         x = x.to(torch.int32)
     elif x.dtype == torch.float64:
         x = x.to(torch.float32)

@@ -163,3 +163,13 @@ def test_integration_md_ctypes_stub_runs_on_the_gpu(dev):
     X = np.concatenate([emb.reshape(B, F, D), dense[:, None, :]], axis=1)
     assert close_dot(z.cpu().numpy()[:, :351], X)
     assert np.array_equal(z.cpu().numpy()[:, 351:], dense)
+
+
+def test_int64_ids_saturate_instead_of_wrapping():
+    """ids beyond int32 must not alias a valid row after the narrowing (2**32 + 5 wrapped to row 5)"""
+    import numpy as np
+    from recamd import nn
+    x = np.array([[0, 5, 2 ** 31 - 1], [2 ** 32 + 5, -(2 ** 40), -3]], dtype=np.int64)
+    got = nn.to_device_ids(x, "cpu")
+    assert got.dtype.is_floating_point is False and got.element_size() == 4
+    assert got.tolist() == [[0, 5, 2 ** 31 - 1], [2 ** 31 - 1, -1, -1]]
