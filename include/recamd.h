@@ -398,6 +398,66 @@ int rec_adam_rows_f32(const rec_table_desc* var, const rec_table_desc* m, const 
                       int64_t ids_stride, int64_t B, float lr, float beta1, float beta2, float eps, int64_t step, float l2,
                       void* stream);
 
+/* ---- T3: backward of the attention-shaped layers and of the remaining heads (csrc/train_attn.hip) -----------------
+ * Attention core on PROJECTED operands laid out as the Dense layers write them: q (B, Nq, H*S), k / v (B, Nk, H*S), head
+ * h = columns [h*S, (h+1)*S), explicit row strides.  out[b,i,h] = softmax_j(scale * q_i . k_j) v_j.  row_mask (B, Nq)
+ * or NULL: a query row whose mask is 0 has EVERY logit replaced by -4294967296.0 (src/match/layers/modules.py:90-91) =>
+ * uniform attention; no gradient reaches that q row or the keys through it.  ctr MultiHeadAttention
+ * (src/ctr/layers/modules.py:221-283): scale = sqrt(S), no mask; match: scale = 1/sqrt(S).  Nk <= 512.
+ * _grad: dout (B, Nq, H*S) -> dq, dk, dv; workspace = rec_attn_core_grad_workspace_bytes (the probabilities and the
+ * logit gradients of every (b, h) pair).  Deterministic. */
+int rec_attn_core_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const float* row_mask, int64_t B, int32_t Nq, int32_t Nk, int32_t H, int32_t S, float scale,
+                      float* out, int64_t ldo, void* stream);
+int64_t rec_attn_core_grad_workspace_bytes(int64_t B, int32_t Nq, int32_t Nk, int32_t H);
+int rec_attn_core_grad_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                           const float* row_mask, const float* dout, int64_t lddo, int64_t B, int32_t Nq, int32_t Nk,
+                           int32_t H, int32_t S, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                           int64_t lddv, void* workspace, void* stream);
+/* Backward of rec_din_attn_pool_f32 (AttentionLayer, src/ctr/layers/modules.py:144-175; contiguous q (B, d), k / v
+ * (B, T, d), mask (B, T) or NULL / mask_is_none = 1 for the all-padding branch): dout (B, d) -> dq (B, d), dk, dv
+ * (B, T, d) and `partials` (B, 4d + 2): per-sample [dW (4d) | dbias | dalpha]; the parameter gradients are their column
+ * sums (rec_colsum_f32).  T <= 256. */
+int rec_din_attn_pool_grad_f32(const float* q, const float* k, const float* v, const float* mask, int32_t mask_is_none,
+                               const float* W, const float* bias, int32_t act, const float* alpha, const float* dout,
+                               int64_t B, int32_t T, int32_t d, float* dq, float* dk, float* dv, float* partials,
+                               void* stream);
+/* tf.keras.layers.PReLU as a Dense activation (src/ctr/din/model.py:52): y = z >= 0 ? z : alpha[n] z on (M, N);
+ * _grad: dz (M, N contiguous) and neg_part = min(z, 0) (dalpha[n] = rec_colsum_f32(dy, neg_part)). */
+int rec_prelu_f32(const float* z, int64_t z_stride, const float* alpha, int64_t M, int64_t N, float* y, int64_t y_stride,
+                  void* stream);
+int rec_prelu_grad_f32(const float* z, int64_t z_stride, const float* alpha, const float* dy, int64_t dy_stride, int64_t M,
+                       int64_t N, float* dz, float* neg_part, void* stream);
+/* Dice (src/ctr/layers/modules.py:327-337) given xn = BatchNormalization(center=False, scale=False)(x) (training: batch
+ * statistics, rec_bn_train_f32): y = alpha (1 - p) x + p x, p = sigmoid(xn); n contiguous elements, alpha one float.
+ * _grad: dx (direct path), dxn (to be taken through rec_bn_train_grad_f32) and dalpha_elem (dalpha = its sum). */
+int rec_dice_train_f32(const float* x, const float* xn, const float* alpha, int64_t n, float* y, void* stream);
+int rec_dice_train_grad_f32(const float* x, const float* xn, const float* alpha, const float* dy, int64_t n, float* dx,
+                      float* dxn, float* dalpha_elem, void* stream);
+/* Backward of rec_layernorm_residual_f32 (y = LN(x + residual) gamma + beta [* row_mask]; contiguous (M, d)): ds =
+ * d(x + residual), xhat and dy_masked (M, d) for dgamma = colsum(dy_masked o xhat), dbeta = colsum(dy_masked). */
+int rec_layernorm_residual_grad_f32(const float* x, const float* residual, const float* gamma, const float* row_mask,
+                                    const float* dy, int64_t M, int32_t d, float eps, float* ds, float* xhat,
+                                    float* dy_masked, void* stream);
+/* dlogits = scale * d rec_pairwise_rank_loss_f32 / d logits  (src/match/sasrec/model.py:93-95) */
+int rec_pairwise_rank_loss_grad_f32(const float* logits, int64_t logits_stride, int64_t B, int32_t n_neg, float scale,
+                                    float* dlogits, int64_t dlogits_stride, void* stream);
+/* Backward of rec_gather_dot_scores_f32 for one table (int32 ids (B, n)): dseq (B, d) [accumulate = 1: +=] and the
+ * looked-up rows' gradients atomically added into grad_table (vocab, d); out-of-range ids contribute nothing. */
+int rec_gather_dot_scores_grad_f32(const float* seq, const float* table, float* grad_table, int64_t vocab, int32_t d,
+                                   const int32_t* ids, int64_t ids_stride, int32_t n, const float* dlogits,
+                                   int64_t dlogits_stride, int64_t B, float* dseq, int32_t accumulate, void* stream);
+/* Backward of rec_fm_onehot_f32 (src/ctr/fm/model.py:34-53) given dlogit (B) = dL/d(pre-sigmoid output): dw (L) and dV
+ * (k, L) receive the gradients of the touched columns by fp32 atomics (zero them first); dw0 = sum(dlogit).
+ * vocab: HOST array of F field sizes; n_dense + F <= 64. */
+int rec_fm_onehot_grad_f32(const float* dense, int64_t dense_stride, int32_t n_dense, const int32_t* ids,
+                           int64_t ids_stride, int32_t F, const int32_t* vocab, const float* V, int32_t k,
+                           const float* dlogit, int64_t B, float* dw, float* dV, void* stream);
+/* tf.keras.layers.Dropout(rate) in training mode: y[e] = keep(seed, e) ? x[e] / (1 - rate) : 0 with a counter-based
+ * mask (splitmix64 of seed and the element index; TensorFlow's own stream cannot be reproduced — parity unpinned by
+ * construction).  The backward pass is the same call on dy.  In place (y == x) allowed. */
+int rec_dropout_f32(const float* x, int64_t n, float rate, uint64_t seed, float* y, void* stream);
+
 /* ---- P1: the step before the path, on the device --------------------------------------------------
  * Raw columns arrive over PCIe; these kernels turn them into what the models take.
  * rec_label_encode_u32: sklearn LabelEncoder.transform of src/ctr/utils/data_process.py:66-68.  tokens (B, F) uint32

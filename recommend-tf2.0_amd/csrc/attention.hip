@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void din_gather_pool_grp_kernel(const float* _
       for (int tt = 0; tt < NTAB; ++tt) {
         const int32_t id = sid[t * NTAB + tt];
         const bool ok = (uint32_t)id < (uint32_t)tb.vocab[tt];
-        const f32x4 row = *reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4);
+        const f32x4 row = row_load<false>(reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
         kr[e][tt] = ok ? row : z4;
       }
     }

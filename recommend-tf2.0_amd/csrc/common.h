@@ -66,6 +66,17 @@ __device__ __forceinline__ int32_t load_id(const void* ids, int64_t idx) {
   return reinterpret_cast<const int32_t*>(ids)[idx];
 }
 
+// 16-B piece of a table row that a launch reads exactly once.  NT = streaming (nt) policy: tools/exp/rowsize_ceiling.hip
+// measured uniformly random rows of 128 B - 1 KiB at 6.0-6.1 TB/s with the default policy and 6.6-6.8 TB/s with nt,
+// whatever the row size.  In the fused kernels (tools/exp/rows_nt_ab.sh, same box): SASRec one-launch 94.0 -> 89.3 us
+// with nt (shipped), DIN pooling 67.4 -> 71.4 us (its three 256-B pieces per slot keep the default policy).
+typedef float rec_f32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ rec_f32x4_t row_load(const rec_f32x4_t* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -613,5 +613,93 @@ PYBIND11_MODULE(_C, m) {
                                   P<float>(out_prob), P<float>(out_fields), P<int32_t>(oob), P<void>(stream)),
           "rec_autoint_forward_f32");
   });
-}
 
+  // ---- T3: attention-shaped backward kernels (csrc/train_attn.hip) ------------------------------------------
+  m.def("attn_core_f32", [](ptr_t q, int64_t ldq, ptr_t k, int64_t ldk, ptr_t v, int64_t ldv, ptr_t mask, int64_t B, int Nq,
+                            int Nk, int H, int S, float scale, ptr_t out, int64_t ldo, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_attn_core_f32(P<const float>(q), ldq, P<const float>(k), ldk, P<const float>(v), ldv, P<const float>(mask), B,
+                            Nq, Nk, H, S, scale, P<float>(out), ldo, P<void>(stream)),
+          "rec_attn_core_f32");
+  });
+  m.def("attn_core_grad_workspace_bytes", [](int64_t B, int Nq, int Nk, int H) {
+    return rec_attn_core_grad_workspace_bytes(B, Nq, Nk, H);
+  });
+  m.def("attn_core_grad_f32", [](ptr_t q, int64_t ldq, ptr_t k, int64_t ldk, ptr_t v, int64_t ldv, ptr_t mask, ptr_t dout,
+                                 int64_t lddo, int64_t B, int Nq, int Nk, int H, int S, float scale, ptr_t dq, int64_t lddq,
+                                 ptr_t dk, int64_t lddk, ptr_t dv, int64_t lddv, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_attn_core_grad_f32(P<const float>(q), ldq, P<const float>(k), ldk, P<const float>(v), ldv,
+                                 P<const float>(mask), P<const float>(dout), lddo, B, Nq, Nk, H, S, scale, P<float>(dq), lddq,
+                                 P<float>(dk), lddk, P<float>(dv), lddv, P<void>(ws), P<void>(stream)),
+          "rec_attn_core_grad_f32");
+  });
+  m.def("din_attn_pool_grad_f32", [](ptr_t q, ptr_t k, ptr_t v, ptr_t mask, int mask_is_none, ptr_t W, ptr_t bias, int act,
+                                     ptr_t alpha, ptr_t dout, int64_t B, int T, int d, ptr_t dq, ptr_t dk, ptr_t dv,
+                                     ptr_t partials, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_din_attn_pool_grad_f32(P<const float>(q), P<const float>(k), P<const float>(v), P<const float>(mask),
+                                     mask_is_none, P<const float>(W), P<const float>(bias), act, P<const float>(alpha),
+                                     P<const float>(dout), B, T, d, P<float>(dq), P<float>(dk), P<float>(dv),
+                                     P<float>(partials), P<void>(stream)),
+          "rec_din_attn_pool_grad_f32");
+  });
+  m.def("prelu_f32", [](ptr_t z, int64_t zs, ptr_t alpha, int64_t M, int64_t N, ptr_t y, int64_t ys, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_prelu_f32(P<const float>(z), zs, P<const float>(alpha), M, N, P<float>(y), ys, P<void>(stream)), "rec_prelu_f32");
+  });
+  m.def("prelu_grad_f32", [](ptr_t z, int64_t zs, ptr_t alpha, ptr_t dy, int64_t dys, int64_t M, int64_t N, ptr_t dz,
+                             ptr_t neg_part, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_prelu_grad_f32(P<const float>(z), zs, P<const float>(alpha), P<const float>(dy), dys, M, N, P<float>(dz),
+                             P<float>(neg_part), P<void>(stream)),
+          "rec_prelu_grad_f32");
+  });
+  m.def("dice_train_f32", [](ptr_t x, ptr_t xn, ptr_t alpha, int64_t n, ptr_t y, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dice_train_f32(P<const float>(x), P<const float>(xn), P<const float>(alpha), n, P<float>(y), P<void>(stream)),
+          "rec_dice_train_f32");
+  });
+  m.def("dice_train_grad_f32", [](ptr_t x, ptr_t xn, ptr_t alpha, ptr_t dy, int64_t n, ptr_t dx, ptr_t dxn, ptr_t da, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dice_train_grad_f32(P<const float>(x), P<const float>(xn), P<const float>(alpha), P<const float>(dy), n, P<float>(dx),
+                            P<float>(dxn), P<float>(da), P<void>(stream)),
+          "rec_dice_train_grad_f32");
+  });
+  m.def("layernorm_residual_grad_f32", [](ptr_t x, ptr_t r, ptr_t gamma, ptr_t mask, ptr_t dy, int64_t M, int d, float eps,
+                                          ptr_t ds, ptr_t xhat, ptr_t dym, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_layernorm_residual_grad_f32(P<const float>(x), P<const float>(r), P<const float>(gamma), P<const float>(mask),
+                                          P<const float>(dy), M, d, eps, P<float>(ds), P<float>(xhat), P<float>(dym),
+                                          P<void>(stream)),
+          "rec_layernorm_residual_grad_f32");
+  });
+  m.def("pairwise_rank_loss_grad_f32", [](ptr_t logits, int64_t ls, int64_t B, int n_neg, float scale, ptr_t dl, int64_t ds,
+                                          ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_pairwise_rank_loss_grad_f32(P<const float>(logits), ls, B, n_neg, scale, P<float>(dl), ds, P<void>(stream)),
+          "rec_pairwise_rank_loss_grad_f32");
+  });
+  m.def("gather_dot_scores_grad_f32", [](ptr_t seq, ptr_t table, ptr_t gtable, int64_t vocab, int d, ptr_t ids,
+                                         int64_t ids_stride, int n, ptr_t dl, int64_t dls, int64_t B, ptr_t dseq,
+                                         int accumulate, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_gather_dot_scores_grad_f32(P<const float>(seq), P<const float>(table), P<float>(gtable), vocab, d,
+                                         P<const int32_t>(ids), ids_stride, n, P<const float>(dl), dls, B, P<float>(dseq),
+                                         accumulate, P<void>(stream)),
+          "rec_gather_dot_scores_grad_f32");
+  });
+  m.def("fm_onehot_grad_f32", [](ptr_t dense, int64_t dense_stride, int n_dense, ptr_t ids, int64_t ids_stride,
+                                 const std::vector<int32_t>& vocab, ptr_t V, int k, ptr_t dlogit, int64_t B, ptr_t dw, ptr_t dV,
+                                 ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_fm_onehot_grad_f32(P<const float>(dense), dense_stride, n_dense, P<const int32_t>(ids), ids_stride,
+                                 (int32_t)vocab.size(), vocab.data(), P<const float>(V), k, P<const float>(dlogit), B,
+                                 P<float>(dw), P<float>(dV), P<void>(stream)),
+          "rec_fm_onehot_grad_f32");
+  });
+  m.def("dropout_f32", [](ptr_t x, int64_t n, float rate, uint64_t seed, ptr_t y, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dropout_f32(P<const float>(x), n, rate, seed, P<float>(y), P<void>(stream)), "rec_dropout_f32");
+  });
+}

@@ -36,6 +36,10 @@
 namespace rec {
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef REC_SASREC_ROWS_NT
+#define REC_SASREC_ROWS_NT 1
+#endif
+constexpr bool kRowsNT = REC_SASREC_ROWS_NT != 0;   // streaming row loads: 94.0 -> 89.3 us at configs[4] (common.h row_load)
 
 constexpr int kD = 64;       // d_model
 constexpr int kWaves = 16;   // per workgroup
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int r = r0 + 4 * u + grp;
-        kr[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr1] * kD);
+        kr[u] = row_load<kRowsNT>(reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr1] * kD));
       }
     };
     issue_rows(ka, 0);
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
         const int j = jb + 4 * u + grp;
         const int32_t id = cand_id(j);
         const float* tp = (j < n_pos ? pos_t : neg_t) + sub * 4;
-        kr[u] = *reinterpret_cast<const f32x4*>(tp + (int64_t)(id >= 0 ? id : 0) * kD);
+        kr[u] = row_load<kRowsNT>(reinterpret_cast<const f32x4*>(tp + (int64_t)(id >= 0 ? id : 0) * kD));
       }
     };
     issue_cand(ka, 0);
