@@ -8,6 +8,9 @@ src/ctr/deep_fm/model.py:50-65, src/ctr/dcn/model.py:45-57 — with BatchNormali
 binary cross-entropy on probabilities (clip + eps inside the logs) and tf.keras.optimizers.Adam (TF2 defaults), the
 models' l2 regularisers added to the loss exactly as Keras does (embeddings_regularizer=l2(c): c * sum(w^2)).
 
+The attention-shaped models of recamd/train_attn.py (classic FM, AutoInt, DIN, SASRec) are restated with the functions of
+oracle/ref_torch.py under autograd.
+
 Weights travel as {name: ndarray} with the names of recamd.train.named_weights."""
 import numpy as np
 import torch
@@ -108,9 +111,11 @@ def keras_bce(p, y):
 
 
 def l2_of(name, l2):
+    if name in l2:
+        return l2[name]
     best = 0.0
     for k, c in l2.items():
-        if name == k or name.startswith(k) or name.endswith(k):
+        if len(k) > 1 and (name.startswith(k) or name.endswith(k)):
             best = c
     return best
 
@@ -144,31 +149,153 @@ class AdamOracle:
             W[k] = W[k] - lr_t * m / (np.sqrt(v) + self.eps)
 
 
+# ---- the attention-shaped models (recamd/train_attn.py): forwards restated with oracle/ref_torch.py's functions, which are
+# differentiable when they are handed fp64 tensors that require grad ---------------------------------------------------
+def fm_forward(P, dense_in, ids, vocab):
+    """src/ctr/fm/model.py:34-53 (explicit one-hot form)"""
+    from . import ref_torch
+    return ref_torch.fm_model(T(dense_in), ids, vocab, P["w0"], P["w"], P["V"]).reshape(-1)
+
+
+def autoint_forward(P, dense_in, ids, H, S, activation="relu", use_res=False):
+    """AutoInt, intended (B, fields, D) form: src/ctr/autoint/model.py:44-55 + src/ctr/layers/modules.py:285-325"""
+    from . import ref_torch
+    ids = np.asarray(ids)
+    B, F = ids.shape
+    emb = gather_concat(P, ids)
+    D = emb.shape[1] // F
+    h = emb.view(B, F, D)
+    if "dense_embed" in P:
+        h = torch.cat([h, T(dense_in)[:, :, None] * P["dense_embed"][None]], dim=1)
+    li = 0
+    while f"attention_{li}/Wq" in P:
+        pre = f"attention_{li}/"
+        h = ref_torch.mha_ctr(h, h, h, P[pre + "Wq"], P[pre + "Wk"], P[pre + "Wv"], P.get(pre + "W0") if use_res else None,
+                              H, S, activation)
+        li += 1
+    return torch.sigmoid(h.reshape(B, -1) @ P["final_dense/kernel"] + P["final_dense/bias"]).reshape(-1)
+
+
+def _table(P, name, ids):
+    tab = P[name]
+    idx = torch.as_tensor(np.trunc(np.asarray(ids, np.float64)).astype(np.int64))
+    ok = (idx >= 0) & (idx < tab.shape[0])
+    return tab[idx.clamp(0, tab.shape[0] - 1)] * ok[..., None].to(torch.float64)
+
+
+def din_forward(P, inputs, user_keys, item_keys, maxlen, att_activation, ffn_activation, n_ffn, training=True,
+                new_moving=None):
+    """DIN, canonical form: src/ctr/din/model.py:57-93 with AttentionLayer (src/ctr/layers/modules.py:144-175) as the
+    pooling; ffn Dense(PReLU() | Dice()); BatchNormalization on batch statistics when training"""
+    from . import ref_torch
+    new_moving = {} if new_moving is None else new_moving
+    user_dense, user_sparse, item_dense, item_sparse, behavior = [np.asarray(a, np.float64) for a in inputs]
+    ue = torch.cat([_table(P, f"embed_{k}/embeddings", user_sparse[:, i]) for i, k in enumerate(user_keys)], dim=-1)
+    ie = torch.cat([_table(P, f"embed_{k}/embeddings", item_sparse[:, i]) for i, k in enumerate(item_keys)], dim=-1)
+    n_item = len(item_keys)
+    beh = torch.stack([torch.cat([_table(P, f"embed_{k}/embeddings", behavior[:, ml * n_item + i])
+                                  for i, k in enumerate(item_keys)], dim=-1) for ml in range(maxlen)], dim=1)
+    mask = torch.as_tensor((np.trunc(behavior[:, ::n_item]) != 0).astype(np.float64))
+    att = ref_torch.din_attention(ie, beh, beh, mask, P["attention_layer/kernel"], P["attention_layer/bias"], att_activation,
+                                  P.get("attention_layer/alpha"))
+    x = torch.cat([T(user_dense), ue, T(item_sparse), ie, att], dim=-1)
+    x = bn_train(x, P, "bn", new_moving) if training else bn_infer(x, P, "bn")
+    for i in range(n_ffn):
+        z = x @ P[f"ffn_{i}/kernel"] + P[f"ffn_{i}/bias"]
+        if ffn_activation == "prelu":
+            x = torch.where(z >= 0, z, P[f"ffn_{i}/prelu/alpha"] * z)
+        else:
+            pre = f"ffn_{i}/dice/bn"
+            if training:
+                mu, var = z.mean(dim=0), z.var(dim=0, unbiased=False)
+                new_moving[pre + "/moving_mean"] = (P[pre + "/moving_mean"] * BN_MOM + mu * (1 - BN_MOM)).detach()
+                new_moving[pre + "/moving_variance"] = (P[pre + "/moving_variance"] * BN_MOM + var * (1 - BN_MOM)).detach()
+            else:
+                mu, var = P[pre + "/moving_mean"], P[pre + "/moving_variance"]
+            pz = torch.sigmoid((z - mu) / torch.sqrt(var + BN_EPS))
+            a = P[f"ffn_{i}/dice/alpha"]
+            x = a * (1.0 - pz) * z + pz * z
+    return torch.sigmoid(x @ P["final_output/kernel"] + P["final_output/bias"]).reshape(-1)
+
+
+def sasrec_forward(P, seq, pos, neg, n_blocks, H, eps=1e-6):
+    """src/match/sasrec/model.py:60-97 -> (logits, add_loss)"""
+    from . import ref_torch
+    blocks = []
+    for b in range(n_blocks):
+        e = f"encoder_{b}/"
+        blocks.append(dict(Wq=P[e + "mha/wq/kernel"], bq=P[e + "mha/wq/bias"], Wk=P[e + "mha/wk/kernel"], bk=P[e + "mha/wk/bias"],
+                           Wv=P[e + "mha/wv/kernel"], bv=P[e + "mha/wv/bias"], ln1_g=P[e + "layernorm1/gamma"],
+                           ln1_b=P[e + "layernorm1/beta"], W1=P[e + "ffn/conv1/kernel"], b1=P[e + "ffn/conv1/bias"],
+                           W2=P[e + "ffn/conv2/kernel"], b2=P[e + "ffn/conv2/bias"], ln2_g=P[e + "layernorm2/gamma"],
+                           ln2_b=P[e + "layernorm2/beta"]))
+    return ref_torch.sasrec(seq, pos, neg, P["user_embed_seq_item/embeddings"], P["user_embed_pos_item/embeddings"],
+                            P["user_embed_neg_item/embeddings"], blocks, H, eps)
+
+
+def dropout_mask(n, rate, seed):
+    """keep mask of rec_dropout_f32 (csrc/train_attn.hip): splitmix64 finaliser of seed * K + e, upper 32 bits >= rate * 2^32"""
+    M = (1 << 64) - 1
+    e = np.arange(n, dtype=np.uint64)
+    x = (np.uint64((seed * 0xD1342543DE82EF95) & M) + e)          # wraps mod 2^64
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    r = (x >> np.uint64(32)).astype(np.uint64)
+    t = float(rate) * 4294967296.0
+    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    return r >= np.uint64(thresh)
+
+
+def _forward(kind, P, inputs, training, new_moving, kw):
+    if kind == "dlrm":
+        return dlrm_forward(P, inputs[0], np.asarray(inputs[1]), kw.get("interaction", "dot"), training=training,
+                            new_moving=new_moving), None
+    if kind == "deepfm":
+        return deepfm_forward(P, inputs[0], np.asarray(inputs[1]), training=training, new_moving=new_moving), None
+    if kind == "dcn":
+        return dcn_forward(P, np.asarray(inputs), training=training, new_moving=new_moving), None
+    if kind == "fm":
+        return fm_forward(P, inputs[0], np.asarray(inputs[1]), kw["vocab"]), None
+    if kind == "autoint":
+        return autoint_forward(P, inputs[0], inputs[1], kw["H"], kw["S"], kw.get("activation", "relu"), kw.get("use_res", False)), None
+    if kind == "din":
+        return din_forward(P, inputs, kw["user_keys"], kw["item_keys"], kw["maxlen"], kw["att_activation"], kw["ffn_activation"],
+                           kw["n_ffn"], training=training, new_moving=new_moving), None
+    if kind == "sasrec":
+        return sasrec_forward(P, inputs[0], inputs[1], inputs[2], kw["n_blocks"], kw.get("H", 1), kw.get("eps", 1e-6))
+    raise ValueError(kind)
+
+
 def train_step(kind, W, opt, inputs, y, l2, **kw):
-    """One Keras training step on {name: ndarray} weights W (updated in place).  Returns (predictions, BCE, reg loss)."""
+    """One Keras training step on {name: ndarray} weights W (updated in place).  Returns (predictions, loss, reg loss);
+    loss = mean Keras BCE against y, or the model's add_loss for 'sasrec' (y = None, predictions = logits)."""
     P = {k: T(v, grad=not is_moving(k)) for k, v in W.items()}
     new_moving = {}
-    if kind == "dlrm":
-        p = dlrm_forward(P, inputs[0], np.asarray(inputs[1]), kw.get("interaction", "dot"), training=True, new_moving=new_moving)
-    elif kind == "deepfm":
-        p = deepfm_forward(P, inputs[0], np.asarray(inputs[1]), training=True, new_moving=new_moving)
-    else:
-        p = dcn_forward(P, np.asarray(inputs), training=True, new_moving=new_moving)
-    bce = keras_bce(p, T(y).reshape(-1))
+    p, own_loss = _forward(kind, P, inputs, True, new_moving, kw)
+    loss = own_loss if own_loss is not None else keras_bce(p, T(y).reshape(-1))
     reg = reg_loss(P, l2)
-    (bce + reg).backward()
+    (loss + reg).backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in P.items() if v.requires_grad}
     opt.apply(W, {k: g for k, g in grads.items() if g is not None})
     for k, v in new_moving.items():
         W[k] = v.numpy()
-    return p.detach().numpy(), float(bce), float(reg)
+    return p.detach().numpy(), float(loss), float(reg)
+
+
+def gradients(kind, W, inputs, y, **kw):
+    """{name: dLoss/dW} of one batch without the regularisers or the optimiser (kernel-level backward checks)"""
+    P = {k: T(v, grad=not is_moving(k)) for k, v in W.items()}
+    p, own_loss = _forward(kind, P, inputs, True, {}, kw)
+    loss = own_loss if own_loss is not None else keras_bce(p, T(y).reshape(-1))
+    loss.backward()
+    return {k: v.grad.numpy() for k, v in P.items() if v.requires_grad and v.grad is not None}, float(loss)
 
 
 def predict(kind, W, inputs, **kw):
     P = {k: T(v) for k, v in W.items()}
     with torch.no_grad():
-        if kind == "dlrm":
-            return dlrm_forward(P, inputs[0], np.asarray(inputs[1]), kw.get("interaction", "dot"), training=False).numpy()
-        if kind == "deepfm":
-            return deepfm_forward(P, inputs[0], np.asarray(inputs[1]), training=False).numpy()
-        return dcn_forward(P, np.asarray(inputs), training=False).numpy()
+        p, _ = _forward(kind, P, inputs, False, {}, kw)
+        return p.numpy()

@@ -25,6 +25,7 @@ class AutoInt(Model):
         if mode not in ('intended', 'as_written'):
             raise ValueError("mode must be 'intended' or 'as_written'")
         self.mode = mode
+        self.embed_reg = embed_reg
         self.dense_feature_columns, self.sparse_feature_columns = feature_columns
         self.embed_layers = {
             'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
@@ -43,7 +44,7 @@ class AutoInt(Model):
         self.attention_layers = [self.track('attention_%d' % i, MultiHeadAttention(
             head_size=att_hidden_units, head_num=head_num, activation=att_activation, use_res=use_res))
             for i in range(att_layer_num)]
-        self.attention_layer = self.attention_layers[0]
+        self.__dict__['attention_layer'] = self.attention_layers[0]     # alias of attention_0 (autoint/model.py:40): not tracked twice
         self.embed_dense = embed_dense and self.nd > 0 and mode == 'intended'
         if self.embed_dense:
             D = self._group.dims[0]

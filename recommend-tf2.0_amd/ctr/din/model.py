@@ -26,6 +26,7 @@ class DIN(Model):
         if mode not in ('intended', 'as_written'):
             raise ValueError("mode must be 'intended' or 'as_written'")
         self.mode = mode
+        self.embed_reg = embed_reg
         self.fuse_history = fuse_history
         self.maxlen = maxlen
         self.sparse_feature_dict = sparse_feature_dict

@@ -12,6 +12,7 @@ class FM(Model):
         self.feature_length = sum(feat['feat_num'] for feat in self.sparse_feature_columns) \
             + len(self.dense_feature_columns)
         self.k = k
+        self.w_reg, self.v_reg = w_reg, v_reg                                        # fm/model.py:19-20 (l2 on w and V)
         self.w0 = self.add_weight('w0', (1,), 'zeros')                              # fm/model.py:22-24
         self.w = self.add_weight('w', (self.feature_length, 1), 'random_normal')   # :25-28
         self.V = self.add_weight('V', (self.k, self.feature_length), 'random_normal')  # :29-32 (k, L)

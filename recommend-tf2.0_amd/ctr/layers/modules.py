@@ -40,6 +40,7 @@ class CrossNetwork(nn.Layer):
     def __init__(self, layer_num, reg_w=1e-6, reg_b=1e-6):
         super().__init__()
         self.layer_num = layer_num
+        self.reg_w, self.reg_b = reg_w, reg_b      # l2 coefficients of w_i / b_i (:92, :100), training only
         self.built = False
 
     def build(self, dim):
@@ -129,8 +130,9 @@ class MultiHeadAttention(nn.Layer):
     """AutoInt interacting layer (src/ctr/layers/modules.py:177-325).  The reference creates its
     Dense layers inside call() (:255-269, :317); here they are explicit weights built on first use."""
 
-    def __init__(self, head_size, head_num=1, l2_reg=None, activation='relu', use_res=False, name=''):
+    def __init__(self, head_size, head_num=1, l2_reg=1e-4, activation='relu', use_res=False, name=''):
         super().__init__(name or None)
+        self._l2_reg = l2_reg          # coefficient of the reference's kernel_regularizer=l2(1e-4) (:179), training only
         self._head_num = head_num
         self._head_size = head_size
         self._activation = activation

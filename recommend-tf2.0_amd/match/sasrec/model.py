@@ -31,6 +31,7 @@ class SASRec(Model):
         else:
             self._shard_rw, self._sharded = (tuple(sharded) if sharded is not None else None), None
         self.seq_len = seq_len
+        self.embed_reg = embed_reg
         self.neg_len = neg_len
         self.user_sparse_feature_columns = user_sparse_feature_columns
         self.user_dense_feature_columns = user_dense_feature_columns

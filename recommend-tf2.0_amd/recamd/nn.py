@@ -164,7 +164,9 @@ class Dense(Layer):
         super().__init__(name, device)
         self.units = int(units)
         self.use_bias = use_bias
-        self.activation = activation
+        # a PReLU() / Dice() instance is tracked ONCE, under 'prelu' / 'dice' (build): bypass Layer.__setattr__, which
+        # would register it a second time as child 'activation' (every weight twice in get_weights / named_weights)
+        self.__dict__["activation"] = activation
         self.built = False
 
     def build(self, in_dim: int):

@@ -63,9 +63,10 @@ def sum_squares(t: torch.Tensor) -> torch.Tensor:
 class Tape:
     """Backward closures in forward order; `grads` collects parameter gradients by name."""
 
-    def __init__(self):
+    def __init__(self, seed: int = 0):
         self.ops: List[Callable[[], None]] = []
         self.grads: Dict[str, torch.Tensor] = {}
+        self.seed = seed          # Dropout masks are a function of (seed, position on the tape)
 
     def add_grad(self, name: str, g: torch.Tensor):
         if name in self.grads:
@@ -92,13 +93,18 @@ class Var:
 
 # ---- training-mode layers ----------------------------------------------------------------------------------------
 def dense_fwd(tape: Tape, layer: nn.Dense, name: str, x: Var) -> Var:
-    """Dense(units, activation): y = act(x W + b); backward = act', column sums, two GEMMs on transposed operands."""
+    """Dense(units, activation): y = act(x W + b); backward = act', column sums, two GEMMs on transposed operands.
+    `activation` may be a PReLU() / Dice() layer instance (src/ctr/din/model.py:52): the pre-activation is kept and the
+    activation runs as its own tape op (rec_prelu_* / rec_dice_train_* around a training-mode BatchNormalization)."""
     xin = x.v if x.v.stride(1) == 1 and x.v.dim() == 2 else x.v.contiguous()
     if not layer.built:
         layer.build(xin.shape[-1])
     act = layer.activation
-    if act is not None and not isinstance(act, str):
-        raise NotImplementedError("training: Dense with a PReLU / Dice layer activation has no backward here")
+    layer_act = act if isinstance(act, (nn.PReLU, nn.Dice)) else None
+    if layer_act is not None:
+        act = None
+    elif act is not None and not isinstance(act, str):
+        raise NotImplementedError(f"training: Dense with activation {act!r} has no backward here")
     W, b = layer._w["kernel"], layer._w.get("bias")
     y = Var(ops.dense(xin, W, b, act))
 
@@ -113,6 +119,50 @@ def dense_fwd(tape: Tape, layer: nn.Dense, name: str, x: Var) -> Var:
         xc = xin if xin.is_contiguous() else xin.contiguous()
         tape.add_grad(name + "/kernel", ops.dense(transpose(xc), dy))          # dW = X^T dY
         x.acc(ops.dense(dy, transpose(W)))                                      # dX = dY W^T
+    tape.ops.append(bwd)
+    if isinstance(layer_act, nn.PReLU):
+        return prelu_fwd(tape, layer_act, name + "/prelu", y)
+    if isinstance(layer_act, nn.Dice):
+        return dice_fwd(tape, layer_act, name + "/dice", y)
+    return y
+
+
+def prelu_fwd(tape: Tape, prelu: nn.PReLU, name: str, z: Var) -> Var:
+    """tf.keras.layers.PReLU(): y = z >= 0 ? z : alpha[n] z with a per-feature alpha"""
+    zv = z.v if z.v.is_contiguous() else z.v.contiguous()
+    M, N = zv.shape
+    alpha = prelu._w["alpha"]
+    y = Var(torch.empty_like(zv))
+    C.prelu_f32(zv.data_ptr(), zv.stride(0), alpha.data_ptr(), M, N, y.v.data_ptr(), y.v.stride(0), _s())
+
+    def bwd():
+        dy = y.g if y.g.is_contiguous() else y.g.contiguous()
+        dz, nz = torch.empty_like(zv), torch.empty_like(zv)
+        C.prelu_grad_f32(zv.data_ptr(), zv.stride(0), alpha.data_ptr(), dy.data_ptr(), dy.stride(0), M, N, dz.data_ptr(),
+                         nz.data_ptr(), _s())
+        tape.add_grad(name + "/alpha", colsum(dy, nz))
+        z.acc(dz)
+    tape.ops.append(bwd)
+    return y
+
+
+def dice_fwd(tape: Tape, dice: nn.Dice, name: str, x: Var) -> Var:
+    """Dice (src/ctr/layers/modules.py:333-337), training: p = sigmoid(BatchNormalization(center=False, scale=False)(x)) on
+    BATCH statistics; y = alpha (1 - p) x + p x"""
+    xv = x.v if x.v.is_contiguous() else x.v.contiguous()
+    xn = bn_fwd(tape, dice.bn, name + "/bn", x)
+    alpha = dice._w["alpha"].reshape(1)
+    y = Var(torch.empty_like(xv))
+    C.dice_train_f32(xv.data_ptr(), xn.v.data_ptr(), alpha.data_ptr(), xv.numel(), y.v.data_ptr(), _s())
+
+    def bwd():
+        dy = y.g if y.g.is_contiguous() else y.g.contiguous()
+        dx, dxn, da = torch.empty_like(xv), torch.empty_like(xv), torch.empty_like(xv)
+        C.dice_train_grad_f32(xv.data_ptr(), xn.v.data_ptr(), alpha.data_ptr(), dy.data_ptr(), xv.numel(), dx.data_ptr(),
+                              dxn.data_ptr(), da.data_ptr(), _s())
+        tape.add_grad(name + "/alpha", colsum(colsum(da).view(-1, 1)).reshape(()))
+        x.acc(dx)
+        xn.acc(dxn)              # reaches x through the BatchNormalization backward, which runs after this closure
     tape.ops.append(bwd)
     return y
 
@@ -155,11 +205,13 @@ def bn_fwd(tape: Tape, bn: nn.BatchNormalization, name: str, x: Var, momentum: f
 
 def dnn_fwd(tape: Tape, dnn, name: str, x: Var) -> Var:
     """ctr DNN (src/ctr/layers/modules.py:129-135): BatchNormalization()(x) -> Dense stack -> Dropout(rate)."""
-    if getattr(dnn.dropout, "rate", 0.0):
-        raise NotImplementedError("training with dnn_dropout > 0 is not built (the reference default is 0.)")
     h = bn_fwd(tape, dnn.bn, name + "/bn", x)
     for i, layer in enumerate(dnn.dnn_network):
         h = dense_fwd(tape, layer, f"{name}/dense_{i}", h)
+    rate = getattr(dnn.dropout, "rate", 0.0)
+    if rate:
+        from .train_attn import dropout_fwd
+        h = dropout_fwd(tape, h, rate)
     return h
 
 
@@ -306,9 +358,11 @@ class Adam:
         self.stamp: Dict[str, torch.Tensor] = {}
 
     def _l2_of(self, name: str) -> float:
+        if name in self.l2:
+            return self.l2[name]
         best = 0.0
         for k, c in self.l2.items():
-            if name == k or name.startswith(k) or name.endswith(k):
+            if len(k) > 1 and (name.startswith(k) or name.endswith(k)):
                 best = c
         return best
 
@@ -424,7 +478,9 @@ TRAIN_FORWARDS = {"DLRM": dlrm_train_forward, "DeepFM": deepfm_train_forward, "D
 
 def default_l2(model) -> Dict[str, float]:
     """the regularisers the reference models attach: embeddings_regularizer=l2(embed_reg) on every table
-    (e.g. src/ctr/dlrm/model.py:35, deep_fm/model.py:36) and the FM layer's l2(w_reg) (src/ctr/layers/modules.py:52-55)"""
+    (e.g. src/ctr/dlrm/model.py:35, deep_fm/model.py:36, sasrec/model.py:44), the FM layer's l2(w_reg)
+    (src/ctr/layers/modules.py:52-55), classic FM's l2(w_reg) / l2(v_reg) (src/ctr/fm/model.py:27,31) and the
+    kernel_regularizer=l2(1e-4) default of the ctr MultiHeadAttention's projections (src/ctr/layers/modules.py:179,258-268,320)"""
     l2 = {}
     reg = getattr(model, "embed_reg", None)
     if reg:
@@ -432,15 +488,33 @@ def default_l2(model) -> Dict[str, float]:
     fm = getattr(model, "fm", None)
     if fm is not None and getattr(fm, "w_reg", 0):
         l2["fm/w"] = float(fm.w_reg)
+    cross = getattr(model, "cross_network", None)
+    if cross is not None:
+        if getattr(cross, "reg_w", 0):
+            l2["cross_network/cross_weights"] = float(cross.reg_w)
+        if getattr(cross, "reg_b", 0):
+            l2["cross_network/cross_bias"] = float(cross.reg_b)
+    if type(model).__name__ == "FM":
+        if getattr(model, "w_reg", 0):
+            l2["w"] = float(model.w_reg)
+        if getattr(model, "v_reg", 0):
+            l2["V"] = float(model.v_reg)
+    for i, layer in enumerate(getattr(model, "attention_layers", []) or []):
+        c = getattr(layer, "_l2_reg", None)
+        if c:
+            for n in ("Wq", "Wk", "Wv", "W0"):
+                l2[f"attention_{i}/{n}"] = float(c)
     return l2
 
 
-def compute_gradients(model, state: TrainState, inputs, y_true, grad_scale: float = 1.0):
-    """training-mode forward + backward of one batch: (predictions, mean BCE, {name: dense-parameter gradient});
-    the embedding-table gradients are scatter-added into `state`."""
+def compute_gradients(model, state: TrainState, inputs, y_true, grad_scale: float = 1.0, seed: int = 0):
+    """training-mode forward + backward of one batch: (predictions, loss, {name: dense-parameter gradient}); the
+    embedding-table gradients are scatter-added into `state`.  loss = mean BCE against y_true, or the model's own
+    add_loss when it has no labels (SASRec: y_true = None, predictions = the logits).  `seed` drives the Dropout masks."""
+    from . import train_attn  # noqa: F401  (registers the FM / AutoInt / DIN / SASRec forwards)
     fwd = TRAIN_FORWARDS[type(model).__name__]
-    tape = Tape()
-    y = nn.to_device_f32(y_true, model.device)
+    tape = Tape(seed)
+    y = None if y_true is None else nn.to_device_f32(y_true, model.device)
     p, loss = fwd(tape, state, model, inputs, y, grad_scale)
     tape.backward()
     return p, loss, tape.grads
@@ -456,7 +530,7 @@ def train_step(model, opt: Adam, state: TrainState, inputs, y_true, allreduce: O
     mean loss over the GLOBAL batch — what MirroredStrategy does (src/ctr/fm/train.py:43-45); BatchNormalization
     keeps per-replica batch statistics, as there."""
     dp = allreduce is not None and world > 1
-    p, loss, grads = compute_gradients(model, state, inputs, y_true, 1.0 / world if dp else 1.0)
+    p, loss, grads = compute_gradients(model, state, inputs, y_true, 1.0 / world if dp else 1.0, seed=opt.step_no + 1)
     if dp:  # same order on every replica
         for k in sorted(grads):
             grads[k] = grads[k].contiguous()
@@ -465,6 +539,8 @@ def train_step(model, opt: Adam, state: TrainState, inputs, y_true, allreduce: O
             allreduce(state._grads[k])
     sparse_ids = None
     if opt.sparse:
+        if type(model).__name__ not in ("DLRM", "DeepFM", "DCN"):
+            raise NotImplementedError("Adam(sparse_embeddings=True) is wired for the (B, F) id matrix of DLRM / DeepFM / DCN")
         ids = inputs[1] if isinstance(inputs, (list, tuple)) else inputs
         ids = nn.to_device_ids(ids, model.device)
         sparse_ids = [(_embed_names(ids.shape[1]), ids)]
@@ -501,9 +577,11 @@ class EarlyStopping:
 
 class Trainer:
     """model.compile(loss=binary_crossentropy, optimizer=Adam(lr), metrics=[AUC()]); model.fit(...); model.evaluate(...)
-    for the mirrors that have a training-mode forward (DLRM, DeepFM, DCN)."""
+    for the mirrors that have a training-mode forward (DLRM, DeepFM, DCN here; classic FM, AutoInt, DIN, SASRec in
+    recamd/train_attn.py)."""
 
     def __init__(self, model):
+        from . import train_attn  # noqa: F401  (registers the FM / AutoInt / DIN / SASRec forwards)
         if type(model).__name__ not in TRAIN_FORWARDS:
             raise NotImplementedError(f"no training-mode forward for {type(model).__name__}")
         self.model, self.opt, self.state = model, None, TrainState(model)
@@ -543,44 +621,60 @@ class Trainer:
             outs.append(self.model(self._slice(x, idx)).reshape(-1))
         return torch.cat(outs).cpu().numpy()
 
-    def evaluate(self, x, y, batch_size: int = 4096):
-        """[loss (BCE + regularisation losses, as Keras reports it), AUC] with INFERENCE-mode BatchNormalization"""
+    def evaluate(self, x, y=None, batch_size: int = 4096):
+        """[loss (BCE + regularisation losses, as Keras reports it), AUC] with INFERENCE-mode BatchNormalization / Dropout;
+        y = None: [sample-weighted mean of the model's add_loss over the batches + regularisation losses]"""
+        if y is None:
+            n, tot = self._len(x), 0.0
+            for lo in range(0, n, batch_size):
+                idx = slice(lo, min(n, lo + batch_size))
+                self.model(self._slice(x, idx))
+                tot += float(self.model.losses[-1].item()) * (idx.stop - idx.start)
+            return [tot / n + self.reg_loss()]
         p = torch.from_numpy(self.predict(x, batch_size)).to(self.model.device)
         yt = nn.to_device_f32(np.asarray(y, np.float32).reshape(-1), self.model.device)
         loss = float(ops.binary_crossentropy(yt, p).item()) + self.reg_loss()
         return [loss, float(ops.auc(yt, p).item())]
 
-    def fit(self, x, y, batch_size: int = 32, epochs: int = 1, validation_split: float = 0.0, callbacks=(), shuffle=True,
+    def fit(self, x, y=None, batch_size: int = 32, epochs: int = 1, validation_split: float = 0.0, callbacks=(), shuffle=True,
             seed: int = 0, verbose: int = 0):
         """Keras semantics: the validation set is the LAST `validation_split` fraction (taken before shuffling); the
         epoch's `loss` is the sample-weighted mean of the batch losses (+ the regularisation losses at the end of each
         batch), `auc` is accumulated over the epoch's training predictions.  Shuffling uses numpy's
-        default_rng(seed + epoch).permutation (Keras' own shuffle is unseeded: not reproducible there either)."""
+        default_rng(seed + epoch).permutation (Keras' own shuffle is unseeded: not reproducible there either).
+        y = None: a model whose loss is its own add_loss (SASRec, src/match/sasrec/model.py:93-95) — `loss` only."""
         n = self._len(x)
         n_val = int(n * validation_split)
         n_tr = n - n_val
-        xt, yt_all = self._slice(x, slice(0, n_tr)), np.asarray(y, np.float32).reshape(-1)[:n_tr]
-        xv, yv = self._slice(x, slice(n_tr, n)), np.asarray(y, np.float32).reshape(-1)[n_tr:]
-        history = {"loss": [], "auc": []}
+        has_y = y is not None
+        y_all = np.asarray(y, np.float32).reshape(-1) if has_y else None
+        xt, xv = self._slice(x, slice(0, n_tr)), self._slice(x, slice(n_tr, n))
+        yt_all, yv = (y_all[:n_tr], y_all[n_tr:]) if has_y else (None, None)
+        history = {"loss": [], "auc": []} if has_y else {"loss": []}
         if n_val:
-            history.update(val_loss=[], val_auc=[])
+            history.update(dict(val_loss=[], val_auc=[]) if has_y else dict(val_loss=[]))
         for epoch in range(epochs):
             order = np.random.default_rng(seed + epoch).permutation(n_tr) if shuffle else np.arange(n_tr)
             loss_sum, preds, labels = 0.0, [], []
             for lo in range(0, n_tr, batch_size):
                 idx = order[lo:lo + batch_size]
                 reg = self.reg_loss()          # Keras adds the regularisation losses of the weights the batch SAW
-                p, loss = train_step(self.model, self.opt, self.state, self._slice(xt, idx), yt_all[idx], self.allreduce,
-                                     self.world)
+                p, loss = train_step(self.model, self.opt, self.state, self._slice(xt, idx), yt_all[idx] if has_y else None,
+                                     self.allreduce, self.world)
                 loss_sum += (float(loss.item()) + reg) * len(idx)
-                preds.append(p.reshape(-1))
-                labels.append(yt_all[idx])
-            pt = torch.cat(preds)
-            lt = nn.to_device_f32(np.concatenate(labels), self.model.device)
-            logs = {"loss": loss_sum / n_tr, "auc": float(ops.auc(lt, pt).item())}
+                if has_y:
+                    preds.append(p.reshape(-1))
+                    labels.append(yt_all[idx])
+            logs = {"loss": loss_sum / n_tr}
+            if has_y:
+                lt = nn.to_device_f32(np.concatenate(labels), self.model.device)
+                logs["auc"] = float(ops.auc(lt, torch.cat(preds)).item())
             if n_val:
-                vl, va = self.evaluate(xv, yv, batch_size)
-                logs.update(val_loss=vl, val_auc=va)
+                if has_y:
+                    vl, va = self.evaluate(xv, yv, batch_size)
+                    logs.update(val_loss=vl, val_auc=va)
+                else:
+                    logs.update(val_loss=self.evaluate(xv, None, batch_size)[0])
             for k, v in logs.items():
                 history[k].append(v)
             if verbose:

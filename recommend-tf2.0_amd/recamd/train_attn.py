@@ -1,0 +1,362 @@
+"""Training-mode forwards of the attention-shaped models: classic FM (src/ctr/fm/model.py:34-53, trained by
+src/ctr/fm/train.py:43-67), AutoInt in its (B, fields, D) form (src/ctr/autoint/model.py:44-55 + the interacting layer of
+src/ctr/layers/modules.py:285-325), DIN in its canonical form (src/ctr/din/model.py:57-93 with the AttentionLayer of
+src/ctr/layers/modules.py:137-175; trained by src/ctr/din/train.py:95-114) and SASRec (src/match/sasrec/model.py:60-97, whose
+loss is the add_loss of :93-95).
+
+Same construction as recamd/train.py: a tape of backward closures over explicit HIP kernels (csrc/train_attn.hip for
+the attention cores, the DIN pooling, PReLU / Dice, LayerNormalization, the rank loss, the dot scores, classic FM and
+dropout; the projections / FFN reuse the Dense backward).  No autograd engine, nothing on the CPU."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import nn, ops
+from ._lib import C
+from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, dense_fwd, sigmoid_bce, transpose)
+
+
+# ---- small tape ops ----------------------------------------------------------------------------------------------
+def view_fwd(tape: Tape, x: Var, shape) -> Var:
+    """reshape of a contiguous activation (no copy); the gradient flows back through the inverse view"""
+    src = x.v if x.v.is_contiguous() else x.v.contiguous()
+    y = Var(src.view(*shape))
+
+    def bwd():
+        if y.g is not None:
+            x.acc(y.g.contiguous().view(src.shape))
+    tape.ops.append(bwd)
+    return y
+
+
+def matmul_act_fwd(tape: Tape, x: Var, W: torch.Tensor, gname: str, act) -> Var:
+    """act(x W) for a bare kernel (the ctr MultiHeadAttention builds bias-free Dense layers inside call(),
+    src/ctr/layers/modules.py:255-269): x (M, K) contiguous"""
+    y = Var(ops.dense(x.v, W, None, act))
+
+    def bwd():
+        dy = y.g if y.g.is_contiguous() else y.g.contiguous()
+        if act not in (None, "linear", "none"):
+            dy = dy.clone()
+            C.act_grad_f32(dy.data_ptr(), dy.stride(0), y.v.data_ptr(), y.v.stride(0), dy.shape[0], dy.shape[1],
+                           ops._act_id(act), _s())
+        tape.add_grad(gname, ops.dense(transpose(x.v), dy))
+        x.acc(ops.dense(dy, transpose(W)))
+    tape.ops.append(bwd)
+    return y
+
+
+def dropout_fwd(tape: Tape, x: Var, rate: float) -> Var:
+    """tf.keras.layers.Dropout(rate)(x, training=True) with the library's counter-based mask (rec_dropout_f32); the
+    seed is (tape.seed, position of the layer on the tape), so a step is reproducible and the backward reuses it"""
+    if not rate:
+        return x
+    seed = (int(getattr(tape, "seed", 0)) << 20) + len(tape.ops)
+    xin = x.v if x.v.is_contiguous() else x.v.contiguous()
+    y = Var(torch.empty_like(xin))
+    C.dropout_f32(xin.data_ptr(), xin.numel(), float(rate), seed, y.v.data_ptr(), _s())
+
+    def bwd():
+        g = y.g if y.g.is_contiguous() else y.g.contiguous()
+        dx = torch.empty_like(g)
+        C.dropout_f32(g.data_ptr(), g.numel(), float(rate), seed, dx.data_ptr(), _s())
+        x.acc(dx)
+    tape.ops.append(bwd)
+    return y
+
+
+def attn_core_fwd(tape: Tape, q: Var, k: Var, v: Var, row_mask: Optional[torch.Tensor], H: int, S: int, scale: float) -> Var:
+    """softmax(scale q k^T [query rows with mask 0 -> uniform]) v per (sample, head); q (B, Nq, H*S), k / v (B, Nk, H*S)"""
+    qv, kv, vv = (t.v if t.v.is_contiguous() else t.v.contiguous() for t in (q, k, v))
+    B, Nq, hs = qv.shape
+    Nk = kv.shape[1]
+    out = Var(torch.empty((B, Nq, hs), dtype=torch.float32, device=qv.device))
+    mptr = 0 if row_mask is None else row_mask.data_ptr()
+    C.attn_core_f32(qv.data_ptr(), hs, kv.data_ptr(), hs, vv.data_ptr(), hs, mptr, B, Nq, Nk, H, S, float(scale),
+                    out.v.data_ptr(), hs, _s())
+
+    def bwd():
+        do = out.g if out.g.is_contiguous() else out.g.contiguous()
+        dq, dk, dv = torch.empty_like(qv), torch.empty_like(kv), torch.empty_like(vv)
+        ws = _ws(C.attn_core_grad_workspace_bytes(B, Nq, Nk, H), qv.device)
+        C.attn_core_grad_f32(qv.data_ptr(), hs, kv.data_ptr(), hs, vv.data_ptr(), hs, mptr, do.data_ptr(), hs, B, Nq, Nk, H, S,
+                             float(scale), dq.data_ptr(), hs, dk.data_ptr(), hs, dv.data_ptr(), hs, ws.data_ptr(), _s())
+        q.acc(dq)
+        k.acc(dk)
+        v.acc(dv)
+    tape.ops.append(bwd)
+    return out
+
+
+def add_act_fwd(tape: Tape, a: Var, b: Var, act=None) -> Var:
+    """act(a + b), elementwise (relu / None)"""
+    y = Var(ops.axpby_act(a.v, b.v, 1.0, 1.0, act))
+
+    def bwd():
+        g = y.g if y.g.is_contiguous() else y.g.contiguous()
+        if act not in (None, "linear", "none"):
+            g = g.clone()
+            g2, y2 = g.view(-1, g.shape[-1]), y.v.view(-1, g.shape[-1])
+            C.act_grad_f32(g2.data_ptr(), g2.stride(0), y2.data_ptr(), y2.stride(0), g2.shape[0], g2.shape[1],
+                           ops._act_id(act), _s())
+        a.acc(g)
+        b.acc(g)
+    tape.ops.append(bwd)
+    return y
+
+
+def layernorm_fwd(tape: Tape, ln: nn.LayerNormalization, name: str, x: Var, r: Optional[Var], row_mask=None) -> Var:
+    """LayerNormalization(x + r) [* row_mask] (src/match/layers/modules.py:175,183-185)"""
+    xv = x.v if x.v.is_contiguous() else x.v.contiguous()
+    rv = None if r is None else (r.v if r.v.is_contiguous() else r.v.contiguous())
+    d = xv.shape[-1]
+    if not ln.built:
+        ln.build(d)
+    y = Var(ops.layernorm_residual(xv, rv, ln._w["gamma"], ln._w["beta"], ln.epsilon, row_mask))
+
+    def bwd():
+        dy = y.g if y.g.is_contiguous() else y.g.contiguous()
+        M = xv.numel() // d
+        ds, xhat, dym = torch.empty_like(xv), torch.empty_like(xv), torch.empty_like(xv)
+        C.layernorm_residual_grad_f32(xv.data_ptr(), 0 if rv is None else rv.data_ptr(), ln._w["gamma"].data_ptr(),
+                                      0 if row_mask is None else row_mask.data_ptr(), dy.data_ptr(), M, d,
+                                      float(ln.epsilon), ds.data_ptr(), xhat.data_ptr(), dym.data_ptr(), _s())
+        tape.add_grad(name + "/gamma", colsum(dym.view(M, d), xhat.view(M, d)))
+        tape.add_grad(name + "/beta", colsum(dym.view(M, d)))
+        x.acc(ds)
+        if r is not None:
+            r.acc(ds)
+    tape.ops.append(bwd)
+    return y
+
+
+def din_pool_fwd(tape: Tape, layer, name: str, q: Var, kv: Var, mask: Optional[torch.Tensor]) -> Var:
+    """AttentionLayer([q, k, v, mask]) with k = v = the behaviour embeddings (src/ctr/din/model.py intended form)"""
+    kt = kv.v if kv.v.is_contiguous() else kv.v.contiguous()
+    qt = q.v if q.v.is_contiguous() else q.v.contiguous()
+    B, T, d = kt.shape
+    if not layer.built:
+        layer.build(d)
+    W, bias, alpha = layer._w["kernel"], layer._w["bias"], layer._w.get("alpha")
+    act = layer.activation
+    out = Var(ops.din_attention_pool(qt, kt, kt, mask, W, bias, act, alpha))
+
+    def bwd():
+        do = out.g if out.g.is_contiguous() else out.g.contiguous()
+        dq, dk, dv = torch.empty_like(qt), torch.empty_like(kt), torch.empty_like(kt)
+        part = torch.empty((B, 4 * d + 2), dtype=torch.float32, device=qt.device)
+        C.din_attn_pool_grad_f32(qt.data_ptr(), kt.data_ptr(), kt.data_ptr(), 0 if mask is None else mask.data_ptr(),
+                                 1 if mask is None else 0, W.data_ptr(), bias.data_ptr(), ops._act_id(act), ops._ptr(alpha),
+                                 do.data_ptr(), B, T, d, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), part.data_ptr(), _s())
+        g = colsum(part)
+        tape.add_grad(name + "/kernel", g[:4 * d].reshape(4 * d, 1))
+        tape.add_grad(name + "/bias", g[4 * d:4 * d + 1])
+        if alpha is not None:
+            tape.add_grad(name + "/alpha", g[4 * d + 1:4 * d + 2])
+        q.acc(dq)
+        kv.acc(ops.axpby_act(dk, dv, 1.0, 1.0, None))
+    tape.ops.append(bwd)
+    return out
+
+
+# ---- classic FM ----------------------------------------------------------------------------------------------------
+def fm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """src/ctr/fm/model.py:34-53, training mode (no BatchNormalization / Dropout in this model)."""
+    dense_inputs, sparse_inputs = inputs
+    dense_inputs = nn.to_device_f32(dense_inputs, m.device)
+    ids = nn.to_device_ids(sparse_inputs, m.device)
+    if ids.dtype != torch.int32:
+        ids = ids.to(torch.int32)
+    vocab = [int(feat['feat_num']) for feat in m.sparse_feature_columns]
+    w0, w, V = m._w['w0'], m._w['w'], m._w['V']
+    p = ops.fm_onehot(dense_inputs, ids, vocab, w0, w, V)
+    yt = y_true.reshape(-1).contiguous()
+    loss = ops.binary_crossentropy(yt, p.reshape(-1))
+
+    def bwd():
+        n = yt.numel()
+        dz = torch.empty(n, dtype=torch.float32, device=p.device)
+        C.bce_sigmoid_grad_f32(yt.data_ptr(), p.reshape(-1).data_ptr(), n, grad_scale / n, dz.data_ptr(), _s())
+        dw, dV = torch.zeros_like(w), torch.zeros_like(V)
+        C.fm_onehot_grad_f32(dense_inputs.data_ptr(), dense_inputs.stride(0), dense_inputs.shape[1], ids.data_ptr(),
+                             ids.stride(0), vocab, V.data_ptr(), V.shape[0], dz.data_ptr(), n, dw.data_ptr(), dV.data_ptr(), _s())
+        tape.add_grad("w0", colsum(dz.view(n, 1)))
+        tape.add_grad("w", dw)
+        tape.add_grad("V", dV)
+    tape.ops.append(bwd)
+    return p, loss
+
+
+# ---- AutoInt ---------------------------------------------------------------------------------------------------------
+def _embed_names(n: int):
+    return [f"embed_{i}/embeddings" for i in range(n)]
+
+
+def autoint_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """AutoInt(mode='intended'), training mode: fields (B, F + nd, D) -> stacked interacting layers -> Dense(1) -> sigmoid."""
+    from .train import gather_concat_fwd
+    if m.mode != 'intended':
+        raise NotImplementedError("training: AutoInt(mode='as_written') mixes samples (see ctr/autoint/model.py); train the intended form")
+    dense_inputs, sparse_inputs = inputs
+    dense_inputs = nn.to_device_f32(dense_inputs, m.device)
+    ids = nn.to_device_ids(sparse_inputs, m.device)
+    B, F = ids.shape
+    D = m._group.dims[0]
+    emb = gather_concat_fwd(tape, state, ops.TableGroup(m._group.tables), _embed_names(F), ids)        # (B, F*D), :46
+    if m.embed_dense:
+        E = m._w['dense_embed']
+        nd = E.shape[0]
+        dpart = torch.empty((B, nd * D), dtype=torch.float32, device=m.device)
+        ops.scale_embed(dense_inputs, E, dpart)
+        h = h0 = Var(torch.cat([emb.v, dpart], dim=1).view(B, F + nd, D))
+
+        def bwd_cat():          # `h` is rebound by the layer loop below: the closure keeps its own name
+            g = h0.g.contiguous().view(B, (F + nd) * D)
+            emb.acc(g[:, :F * D].contiguous())
+            gd = g[:, F * D:].contiguous().view(B, nd, D)
+            dE = torch.empty_like(E)
+            for n in range(nd):     # dE[n] = sum_b dense[b, n] g[b, n, :]
+                dE[n] = colsum(gd[:, n, :], row_w=dense_inputs[:, n].contiguous())
+            tape.add_grad("dense_embed", dE)
+        tape.ops.append(bwd_cat)
+        N = F + nd
+    else:
+        h = view_fwd(tape, emb, (B, F, D))
+        N = F
+    for li, L in enumerate(m.attention_layers):
+        din = h.v.shape[-1]
+        if not L.built:
+            L.build(din)
+        H, S, act = L._head_num, L._head_size, L._activation
+        x2 = view_fwd(tape, h, (B * N, din))
+        pre = f"attention_{li}/"
+        q = view_fwd(tape, matmul_act_fwd(tape, x2, L._w['Wq'], pre + "Wq", act), (B, N, H * S))
+        k = view_fwd(tape, matmul_act_fwd(tape, x2, L._w['Wk'], pre + "Wk", act), (B, N, H * S))
+        v = view_fwd(tape, matmul_act_fwd(tape, x2, L._w['Wv'], pre + "Wv", act), (B, N, H * S))
+        att = attn_core_fwd(tape, q, k, v, None, H, S, math.sqrt(float(S)))            # "/ (S ** -0.5)", modules.py:235
+        if L._use_res:
+            r = view_fwd(tape, matmul_act_fwd(tape, x2, L._w['W0'], pre + "W0", act), (B, N, H * S))
+            att = add_act_fwd(tape, att, r, 'relu')                                     # :316-323
+        h = att
+    flat = view_fwd(tape, h, (B, N * h.v.shape[-1]))
+    top = dense_fwd(tape, m.final_dense, "final_dense", flat)
+    return sigmoid_bce(tape, [top], y_true, grad_scale)
+
+
+# ---- DIN ---------------------------------------------------------------------------------------------------------------
+def din_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """DIN(mode='intended'), training mode (src/ctr/din/model.py:57-93 with the AttentionLayer pooling): BatchNormalization on
+    batch statistics (:83), Dense(PReLU() | Dice()) stack (:52,:85-87), Dropout (:89), Dense(1), sigmoid."""
+    from .train import gather_concat_fwd
+    if m.mode != 'intended':
+        raise NotImplementedError("training: DIN as written raises for maxlen > 1; train mode='intended'")
+    user_dense, user_sparse, item_dense, item_sparse, behavior = [nn.to_device_f32(t, m.device) for t in inputs]
+    B = user_sparse.shape[0]
+    to_i32 = lambda t: t.to(torch.int32).contiguous()    # the Keras Embedding cast (truncation toward zero)  # noqa: E731
+    uids = to_i32(m._cols(user_sparse, m._user_cols))
+    iids = to_i32(m._cols(item_sparse, m._item_cols))
+    bids = to_i32(m._cols(behavior, m._beh_cols))
+    if not m._beh_regular:
+        raise NotImplementedError("training: behaviour columns must be maxlen repeats of the item tables")
+    unames = ['embed_' + k + '/embeddings' for k in m.user_sparse_feature_index]
+    inames = ['embed_' + k + '/embeddings' for k in m.item_sparse_feature_index]
+    n_item, T = len(inames), m.maxlen
+    user_emb = gather_concat_fwd(tape, state, ops.TableGroup(m._user_group.tables), unames, uids)       # :62-64
+    item_emb = gather_concat_fwd(tape, state, ops.TableGroup(m._item_group.tables), inames, iids)       # :66-68
+    beh_flat = gather_concat_fwd(tape, state, ops.TableGroup(m._item_group.tables), inames, bids.view(B * T, n_item))  # :71-74
+    d = item_emb.v.shape[1]
+    beh = view_fwd(tape, beh_flat, (B, T, d))
+    mask = (bids.view(B, T, n_item)[:, :, 0] != 0).to(torch.float32).contiguous()
+    att = din_pool_fwd(tape, m.attention_layer, "attention_layer", item_emb, beh, mask)
+    parts = [Var(user_dense), user_emb, Var(item_sparse.contiguous()), item_emb, att]                  # :62-68, :81
+    widths = [p.v.shape[1] for p in parts]
+    allv = Var(torch.cat([p.v for p in parts], dim=-1))
+
+    def bwd_cat():
+        off = 0
+        for p, wdt in zip(parts, widths):
+            if p in (user_emb, item_emb, att):
+                p.acc(allv.g[:, off:off + wdt].contiguous())
+            off += wdt
+    tape.ops.append(bwd_cat)
+    x = bn_fwd(tape, m.bn, "bn", allv)                                                                 # :83
+    for i, dense in enumerate(m.ffn):                                                                  # :85-87
+        x = dense_fwd(tape, dense, f"ffn_{i}", x)
+    x = dropout_fwd(tape, x, getattr(m.dropout, "rate", 0.0))                                           # :89
+    top = dense_fwd(tape, m.final_output, "final_output", x)
+    return sigmoid_bce(tape, [top], y_true, grad_scale)                                               # :91
+
+
+# ---- SASRec ------------------------------------------------------------------------------------------------------------
+def _rows_fwd(tape: Tape, state: TrainState, table: torch.Tensor, name: str, ids: torch.Tensor) -> Var:
+    """Embedding.call on one table for (B, n) int32 ids (out-of-range / -1 -> zero rows, no gradient) -> (B*n, d)"""
+    from .train import gather_concat_fwd
+    return gather_concat_fwd(tape, state, ops.TableGroup([table]), [name], ids.reshape(-1, 1).contiguous())
+
+
+def sasrec_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, grad_scale: float = 1.0):
+    """src/match/sasrec/model.py:60-97, training mode: every block encodes all positions (the gradients of the K / V
+    projections need them); the loss is the model's add_loss (:93-95).  Returns (logits, loss)."""
+    if m._sharded is not None:
+        raise NotImplementedError("training: SASRec with row-sharded tables goes through ShardedTables.backward (recamd.dist)")
+    seq, pos, neg = [nn.to_device_ids(t, m.device) for t in inputs]
+    seq, pos, neg = [t if t.dtype == torch.int32 else t.to(torch.int32) for t in (seq, pos, neg)]
+    B, S = seq.shape
+    n_neg = neg.shape[1]
+    d = m.d_model
+    tb = m.user_embed_layers
+    names = {k: f"user_embed_{k}/embeddings" for k in ("seq_item", "pos_item", "neg_item")}
+    mask = (seq != 0).to(torch.float32).contiguous()                                                    # :72
+    seq_m = torch.where(seq == 0, torch.full_like(seq, -1), seq)            # `seq_embed * mask` (:81-82): pad rows are zero
+    x = _rows_fwd(tape, state, tb['embed_seq_item'].table, names["seq_item"], seq_m)                  # (B*S, d), :75
+    rate = float(getattr(m.dropout, "rate", 0.0) or 0.0)
+    mflat = mask.reshape(-1)
+    for bi, enc in enumerate(m.encoder_layer):                                                          # :84-86
+        pre = f"encoder_{bi}/"
+        mha = enc.mha
+        H = mha.num_heads
+        depth = d // H
+        q = view_fwd(tape, dense_fwd(tape, mha.wq, pre + "mha/wq", x), (B, S, d))
+        k = view_fwd(tape, dense_fwd(tape, mha.wk, pre + "mha/wk", x), (B, S, d))
+        v = view_fwd(tape, dense_fwd(tape, mha.wv, pre + "mha/wv", x), (B, S, d))
+        att = view_fwd(tape, attn_core_fwd(tape, q, k, v, mask, H, depth, 1.0 / math.sqrt(float(depth))), (B * S, d))
+        att = dropout_fwd(tape, att, getattr(enc.dropout1, "rate", 0.0))
+        out1 = layernorm_fwd(tape, enc.layernorm1, pre + "layernorm1", x, att)                          # modules.py:175
+        f = dense_fwd(tape, enc.ffn.conv2, pre + "ffn/conv2", dense_fwd(tape, enc.ffn.conv1, pre + "ffn/conv1", out1))
+        f = dropout_fwd(tape, f, getattr(enc.dropout2, "rate", 0.0))
+        x = layernorm_fwd(tape, enc.layernorm2, pre + "layernorm2", out1, f, row_mask=mflat)            # :183 + `*= mask`
+    xs = x
+    seq_info = Var(xs.v.view(B, S, d)[:, -1, :].contiguous())                                           # :88
+
+    def bwd_last():
+        g = torch.zeros((B, S, d), dtype=torch.float32, device=m.device)
+        g[:, -1, :] = seq_info.g
+        xs.acc(g.view(B * S, d))
+    tape.ops.append(bwd_last)
+    logits = torch.empty((B, 1 + n_neg), dtype=torch.float32, device=m.device)
+    pos_t, neg_t = tb['embed_pos_item'].table, tb['embed_neg_item'].table
+    ops.gather_dot_scores(seq_info.v, pos_t, pos.contiguous(), out=logits[:, :1])                        # :77, :90
+    ops.gather_dot_scores(seq_info.v, neg_t, neg.contiguous(), out=logits[:, 1:])                        # :79, :91
+    loss = ops.pairwise_rank_loss(logits)                                                               # :93-95
+
+    def bwd_loss():
+        dl = torch.empty_like(logits)
+        C.pairwise_rank_loss_grad_f32(logits.data_ptr(), logits.stride(0), B, n_neg, float(grad_scale), dl.data_ptr(),
+                                      dl.stride(0), _s())
+        dseq = torch.empty((B, d), dtype=torch.float32, device=m.device)
+        gp, gn = state.grad(names["pos_item"]), state.grad(names["neg_item"])
+        C.gather_dot_scores_grad_f32(seq_info.v.data_ptr(), pos_t.data_ptr(), gp.data_ptr(), pos_t.shape[0], d, pos.data_ptr(),
+                                     pos.stride(0), pos.shape[1], dl.data_ptr(), dl.stride(0), B, dseq.data_ptr(), 0, _s())
+        C.gather_dot_scores_grad_f32(seq_info.v.data_ptr(), neg_t.data_ptr(), gn.data_ptr(), neg_t.shape[0], d, neg.data_ptr(),
+                                     neg.stride(0), n_neg, dl[:, 1:].data_ptr(), dl.stride(0), B, dseq.data_ptr(), 1, _s())
+        seq_info.acc(dseq)
+    tape.ops.append(bwd_loss)
+    m._logits = logits
+    return logits, loss
+
+
+TRAIN_FORWARDS.update({"FM": fm_train_forward, "AutoInt": autoint_train_forward, "DIN": din_train_forward,
+                       "SASRec": sasrec_train_forward})
