@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void din_gather_pool_lds_kernel(const float* _
 // row), the four groups keep independent online-softmax states that are merged once at the end, the rescale happens once
 // per batch (batch maximum first), and exp is v_exp_f32 on log2(e)-scaled scores: ~14 VALU per slot.
 template <int IDS_F32, int NTAB>
-__global__ __launch_bounds__(256) void din_gather_pool_grp_kernel(const float* __restrict__ q, DinTables tb,
+__global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_kernel(const float* __restrict__ q, DinTables tb,
                                                                   const void* __restrict__ ids,
                                                                   const float* __restrict__ mask, int mask_mode,
                                                                   const float* __restrict__ W,
@@ -463,18 +463,48 @@ __global__ __launch_bounds__(256) void din_gather_pool_grp_kernel(const float* _
 
   // batch = U steps of 4 slots; slot index of (step e, group g) = i0 + 4 e + g; indices past the end re-read the last
   // listed slot (a cache hit) and enter the softmax with the logit -inf
+  // A/B builds (tools/exp/din_ab.sh, configs[3], same box): SKIP = lane groups without a slot issue nothing, NT =
+  // streaming row loads.  SKIP 0 / NT 0 (shipped) 66.9-67.1 us; NT alone 71.0; SKIP (with or without NT) 99-101 us — the
+  // exec-masked loads lose their batching (a wait lands behind every conditional load).
+#ifndef REC_DIN_SKIP
+#define REC_DIN_SKIP 0
+#endif
+#ifndef REC_DIN_NT
+#define REC_DIN_NT 0
+#endif
   auto load_batch = [&](int i0, f32x4 (&kr)[U][NTAB]) {
 #pragma unroll
     for (int e = 0; e < U; ++e) {
       const int i = i0 + 4 * e + grp;
+#if REC_DIN_SKIP
+      // a lane group without a slot issues nothing (its rows enter the softmax with weight 0 whatever kr holds, but NaN
+      // bits would survive the multiply by 0: zeros).  With streaming loads a clamped re-read of the last slot is an
+      // HBM fetch, not a cache hit.
+      if (i < n) {
+        const int t = slots[i] & 0x7fffffff;
+#pragma unroll
+        for (int tt = 0; tt < NTAB; ++tt) {
+          const int32_t id = sid[t * NTAB + tt];
+          const bool ok = (uint32_t)id < (uint32_t)tb.vocab[tt];
+          const f32x4 row = row_load<REC_DIN_NT != 0>(
+              reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
+          kr[e][tt] = ok ? row : z4;
+        }
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < NTAB; ++tt) kr[e][tt] = z4;
+      }
+#else
       const int t = slots[i < n ? i : n - 1] & 0x7fffffff;
 #pragma unroll
       for (int tt = 0; tt < NTAB; ++tt) {
         const int32_t id = sid[t * NTAB + tt];
         const bool ok = (uint32_t)id < (uint32_t)tb.vocab[tt];
-        const f32x4 row = row_load<false>(reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
+        const f32x4 row = row_load<REC_DIN_NT != 0>(
+            reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
         kr[e][tt] = ok ? row : z4;
       }
+#endif
     }
   };
   float m = -INFINITY, l = 0.f;
