@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=16384)
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (gather_roofline, rowshard)")
-    ap.add_argument("--side-timeout", type=float, default=240.0, help="watchdog of the N>1 side placement measurement (s)")
+    ap.add_argument("--side-timeout", type=float, default=150.0, help="watchdog of the N>1 side placement measurement (s)")
     ap.add_argument("--side-leg", action="store_true", help=argparse.SUPPRESS)   # internal: child process of an N>1 run
     return ap.parse_args()
 

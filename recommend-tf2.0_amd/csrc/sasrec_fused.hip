@@ -70,27 +70,41 @@ __device__ __forceinline__ void glds4(const void* g, uint32_t lds) {
       : "memory");
 }
 
-// y[lane] = sum_i x_i W[i][col], x one element per lane, W in LDS with row stride `ld`; four partial sums
-// (the column index is laundered through an empty asm: the weights do not depend on the sample, and without it the
-// compiler hoists all 28 672 / 64 weight reads out of the persistent loop and spills them).
-template <int LD>
-__device__ __forceinline__ float matvec64(const float* __restrict__ W, float x, int col, float init) {
-  float a0 = init, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  // a real loop over blocks of 16 rows (not unrolled): 16 weight reads in registers at a time — the row landing buffers
+// y[lane] = sum_i x_i W[i][col].  W sits in LDS as [i / 4][NCOL columns][4]: lane `col` fetches W[i .. i+3][col] with ONE
+// conflict-free ds_read_b128, x comes from a wave-private LDS vector as a broadcast ds_read_b128 (every lane the same
+// address), and the four products are two v_pk_fma_f32 — 6 instructions (2 VALU) per four terms where the first version
+// spent 12 (v_readlane + ds_read_b32 + v_fmac per term, 8 VALU): the SQ counters had this kernel at ~80 % VALU issue
+// (4 waves per SIMD, 20 % VALU-active each), and the seven matvecs of a sample were ~900 of its ~3 400 VALU
+// instructions.  Same four partial sums (i mod 4) and the same final combination as before: bit-identical results.
+// (The column index is laundered through an empty asm: the weights do not depend on the sample, and without it the
+// compiler hoists all 28 672 / 64 weight reads out of the persistent loop and spills them.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NI, int NCOL>
+__device__ __forceinline__ float matvec_pk(const float* __restrict__ W4, const float* __restrict__ xb, int col, float init) {
+  f32x2 a01 = {init, 0.f}, a23 = {0.f, 0.f};
+  // a real loop over blocks of 16 rows (not unrolled): 4 weight quads in registers at a time — the row landing buffers
   // of the caller hold 64 of the wave's 128 VGPRs while this runs
 #pragma unroll 1
-  for (int i0 = 0; i0 < 64; i0 += 16) {
+  for (int i0 = 0; i0 < NI; i0 += 16) {
     asm volatile("" : "+v"(col));
-    const float* Wb = W + i0 * LD + col;
+    const float* Wb = W4 + ((i0 >> 2) * NCOL + col) * 4;
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
-      a0 = fmaf(bcast(x, i0 + i), Wb[(i)*LD], a0);
-      a1 = fmaf(bcast(x, i0 + i + 1), Wb[(i + 1) * LD], a1);
-      a2 = fmaf(bcast(x, i0 + i + 2), Wb[(i + 2) * LD], a2);
-      a3 = fmaf(bcast(x, i0 + i + 3), Wb[(i + 3) * LD], a3);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(Wb + (i >> 2) * NCOL * 4);
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xb + i0 + i);
+      a01 = __builtin_elementwise_fma(f32x2{x.x, x.y}, f32x2{w.x, w.y}, a01);
+      a23 = __builtin_elementwise_fma(f32x2{x.z, x.w}, f32x2{w.z, w.w}, a23);
     }
   }
-  return (a0 + a1) + (a2 + a3);
+  return (a01.x + a01.y) + (a23.x + a23.y);
+}
+
+// wave-private LDS hand-over: what the lanes wrote is visible to the whole wave afterwards (LDS operations of one wave
+// execute in order, so a later overwrite cannot overtake these reads either)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ float layer_norm64(float v, float g, float b, float eps) {
@@ -115,25 +129,28 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     int64_t neg_stride, int n_neg, int64_t B, float* __restrict__ seq_info, float* __restrict__ logits,
     int64_t logits_stride, int* __restrict__ oob, int lst_cap, int cand_cap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int LDK = 65;                       // padded row stride of Wk^T
-  float* const Wq = lds;                        // [64][64]   (in, out)
-  float* const WkT = Wq + 64 * 64;              // [64 out][65]: WkT[o][i] = Wk[i][o]
-  float* const Wv = WkT + 64 * LDK + 60;        // keep 16-B alignment (64*65 + 60 = 4220 = 4 * 1055)
-  float* const W1 = Wv + 64 * 64;               // [64][FH]
-  float* const W2 = W1 + 64 * FH;               // [FH][64]
+  // weights as [i / 4][columns][4] (matvec_pk): (i, c) at ((i >> 2) * NCOL + c) * 4 + (i & 3)
+  float* const Wq = lds;                        // in 64, out 64
+  float* const WkT = Wq + 64 * 64;              // "in" = o, column = c: WkT(o, c) = Wk[c][o]  (q_back = Wk q)
+  float* const Wv = WkT + 64 * 64;
+  float* const W1 = Wv + 64 * 64;               // in 64, out FH
+  float* const W2 = W1 + 64 * FH;               // in FH, out 64
   float* const vec = W2 + FH * 64;              // bq bv g1 be1 b2 g2 be2 (64 each), b1 (FH)
+  float* const xbuf = vec + 7 * 64 + FH + (threadIdx.x >> 6) * 64;    // per wave: the vector the next matvec consumes
   // per wave: two sequence-id buffers (the list of real rows is compacted in place in the one being consumed, the other
   // receives the next sample's ids), the candidate ids, two mask words
-  int32_t* const wave_lds = reinterpret_cast<int32_t*>(vec + 7 * 64 + FH) + (threadIdx.x >> 6) * (2 * lst_cap + cand_cap + 2);
+  int32_t* const wave_lds = reinterpret_cast<int32_t*>(vec + 7 * 64 + FH + kWaves * 64) + (threadIdx.x >> 6) * (2 * lst_cap + cand_cap + 2);
   const int tid = threadIdx.x;
-  for (int e = tid * 4; e < 64 * 64; e += kWaves * 64 * 4) {
-    *reinterpret_cast<f32x4*>(Wq + e) = *reinterpret_cast<const f32x4*>(P.wq + e);
-    *reinterpret_cast<f32x4*>(Wv + e) = *reinterpret_cast<const f32x4*>(P.wv + e);
+  auto w4 = [](int i, int c, int ncol) { return ((i >> 2) * ncol + c) * 4 + (i & 3); };
+  for (int e = tid; e < 64 * 64; e += kWaves * 64) {       // e = i * 64 + o of the Keras (in, out) kernels
+    const int i = e >> 6, o = e & 63;
+    Wq[w4(i, o, 64)] = P.wq[e];
+    Wv[w4(i, o, 64)] = P.wv[e];
+    WkT[w4(o, i, 64)] = P.wk[e];
   }
-  for (int e = tid; e < 64 * 64; e += kWaves * 64) WkT[(e & 63) * LDK + (e >> 6)] = P.wk[e];   // e = i * 64 + o
-  for (int e = tid * 4; e < 64 * FH; e += kWaves * 64 * 4) {
-    *reinterpret_cast<f32x4*>(W1 + e) = *reinterpret_cast<const f32x4*>(P.w1 + e);
-    *reinterpret_cast<f32x4*>(W2 + e) = *reinterpret_cast<const f32x4*>(P.w2 + e);
+  for (int e = tid; e < 64 * FH; e += kWaves * 64) {
+    W1[w4(e / FH, e % FH, FH)] = P.w1[e];                  // (in 64, out FH)
+    W2[w4(e >> 6, e & 63, 64)] = P.w2[e];                  // (in FH, out 64)
   }
   if (tid < 64) {
     vec[tid] = P.bq[tid];
@@ -220,13 +237,15 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     issue_rows(kb, 4 * kU);
     // ---- last position: x -> q = x Wq + bq -> q_back = Wk q ---------------------------------------------------
     x_last = last_ok ? x_last : 0.f;
-    const float q = matvec64<64>(Wq, x_last, lane, vec[lane]);
-    const float q_back = matvec64<LDK>(WkT, q, lane, 0.f);
-    f32x4 qv;
-    qv.x = __shfl(q_back, sub * 4, 64);
-    qv.y = __shfl(q_back, sub * 4 + 1, 64);
-    qv.z = __shfl(q_back, sub * 4 + 2, 64);
-    qv.w = __shfl(q_back, sub * 4 + 3, 64);
+    xbuf[lane] = x_last;
+    wave_lds_sync();
+    const float q = matvec_pk<64, 64>(Wq, xbuf, lane, vec[lane]);
+    xbuf[lane] = q;                       // the wave has finished reading x_last: its LDS operations are in order
+    wave_lds_sync();
+    const float q_back = matvec_pk<64, 64>(WkT, xbuf, lane, 0.f);
+    xbuf[lane] = q_back;
+    wave_lds_sync();
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(xbuf + sub * 4);     // elements 4 sub .. 4 sub + 3 (the row piece's)
     // ---- attention over the raw rows of the real slots (online softmax per 16-lane group) ---------------------
     const bool masked = mask_last == 0.f;      // masked query row: all logits equal -> uniform over all S keys
     float m = -INFINITY, l = 0.f;
@@ -306,32 +325,28 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
       l = l * s1 + (float)nz * __builtin_amdgcn_exp2f(-mn);
     }
     acc *= 1.f / l;
-    // f32x4-per-sub layout -> one element per lane
-    float pooled;
-    {
-      const int src = lane >> 2;
-      const float t0 = __shfl(acc.x, src, 64), t1 = __shfl(acc.y, src, 64);
-      const float t2 = __shfl(acc.z, src, 64), t3 = __shfl(acc.w, src, 64);
-      const int c = lane & 3;
-      pooled = c == 0 ? t0 : c == 1 ? t1 : c == 2 ? t2 : t3;
-    }
+    // f32x4-per-sub layout -> the matvec's input vector (group 0 holds the merged state)
+    if (grp == 0) *reinterpret_cast<f32x4*>(xbuf + sub * 4) = acc;
+    wave_lds_sync();
     // ---- Wv, LN1, FFN, LN2 * mask -------------------------------------------------------------------------------
-    const float att = matvec64<64>(Wv, pooled, lane, vec[64 + lane]);
+    const float att = matvec_pk<64, 64>(Wv, xbuf, lane, vec[64 + lane]);
     const float out1 = layer_norm64(x_last + att, vec[128 + lane], vec[192 + lane], P.eps1);
     float f = vec[256 + lane];
 #pragma unroll
-    for (int hb = 0; hb < FH / 64; ++hb) {
-      const float h = relu_nan(matvec64<FH>(W1, out1, hb * 64 + lane, vec[448 + hb * 64 + lane]));
-      f = matvec64<64>(W2 + hb * 64 * 64, h, lane, f);
+    for (int hb = 0; hb < FH / 64; ++hb) {      // one 64-float staging vector: out1 is re-staged per block of 64 hidden units
+      xbuf[lane] = out1;
+      wave_lds_sync();
+      const float h = relu_nan(matvec_pk<64, FH>(W1, xbuf, hb * 64 + lane, vec[448 + hb * 64 + lane]));
+      xbuf[lane] = h;
+      wave_lds_sync();
+      f = matvec_pk<64, 64>(W2 + hb * 64 * 64, xbuf, lane, f);
     }
     const float si = layer_norm64(out1 + f, vec[320 + lane], vec[384 + lane], P.eps2) * mask_last;
     if (seq_info) seq_info[b * kD + lane] = si;
     // ---- candidates: logits[b, j] = table_j[id_j] . seq_info ----------------------------------------------------
-    f32x4 sv;
-    sv.x = __shfl(si, sub * 4, 64);
-    sv.y = __shfl(si, sub * 4 + 1, 64);
-    sv.z = __shfl(si, sub * 4 + 2, 64);
-    sv.w = __shfl(si, sub * 4 + 3, 64);
+    xbuf[lane] = si;
+    wave_lds_sync();
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(xbuf + sub * 4);
     auto reduce_cand = [&](f32x4(&kr)[kU], int jb) {
       float mine = 0.f;
 #pragma unroll
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
 
 template <int FH>
 size_t lds_bytes(int lst_cap, int cand_cap) {
-  return (size_t)(64 * 64 + 64 * 65 + 60 + 64 * 64 + 2 * 64 * FH + 7 * 64 + FH) * 4 +
+  return (size_t)(3 * 64 * 64 + 2 * 64 * FH + 7 * 64 + FH + kWaves * 64) * 4 +
          (size_t)kWaves * (2 * lst_cap + cand_cap + 2) * 4;
 }
 
@@ -373,7 +388,7 @@ using namespace rec;
 
 extern "C" int rec_sasrec_last_row_supported(int32_t d, int32_t ffn_hidden, int32_t S, int32_t n_cand) {
   if (d != 64 || (ffn_hidden != 64 && ffn_hidden != 128) || S < 1 || n_cand < 1) return 0;
-  const int lst_cap = (S + 63) & ~63, cand_cap = (n_cand + 63) & ~63;
+  const int lst_cap = (S + 3) & ~3, cand_cap = (n_cand + 3) & ~3;
   const size_t lds = ffn_hidden == 128 ? lds_bytes<128>(lst_cap, cand_cap) : lds_bytes<64>(lst_cap, cand_cap);
   return lds <= 160 * 1024 ? 1 : 0;
 }
@@ -407,8 +422,8 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   SasrecParams P{blk->wq, blk->bq, blk->wk, blk->wv, blk->bv, blk->ln1_gamma, blk->ln1_beta, blk->w1, blk->b1,
                  blk->w2, blk->b2, blk->ln2_gamma, blk->ln2_beta, blk->ln1_eps, blk->ln2_eps, blk->ffn_hidden};
-  const int lst_cap = (S + 63) & ~63;
-  const int cand_cap = (n_pos + n_neg + 63) & ~63;
+  const int lst_cap = (S + 3) & ~3;                       // the id DMAs only touch slots < S / < n_cand
+  const int cand_cap = (n_pos + n_neg + 3) & ~3;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
