@@ -48,6 +48,9 @@ typedef u32x4 __attribute__((address_space(1)))* gdst_t;
 #ifndef REC_GATHER_STORE
 #define REC_GATHER_STORE 0
 #endif
+#ifndef REC_GATHER_LOAD_NT
+#define REC_GATHER_LOAD_NT 0     // 1 = nontemporal row loads (A/B builds)
+#endif
 __device__ __forceinline__ void row_store(u32x4 v, uint64_t addr) {
 #if REC_GATHER_STORE == 0
   __builtin_nontemporal_store(v, reinterpret_cast<gdst_t>(addr));
@@ -60,8 +63,13 @@ __device__ __forceinline__ void row_store(u32x4 v, uint64_t addr) {
 #endif
 }
 
+// 4 blocks per CU = at most 128 VGPRs (D = 128 compiled to 129 without the bound: three waves per SIMD instead of four).
+// Tried in round 2 (same box, tools/exp/gather_load_ab.sh, gather_plain_ab.sh): nontemporal row LOADS 0.680 -> 0.697 on
+// uniform ids but 0.844 -> 0.738 on Zipf ids (REC_GATHER_LOAD_NT, off); destination addresses computed instead of
+// shuffled for the plain concat layout (92 VGPRs, five waves per SIMD): no gain, removed.  What does move this kernel by
+// 7 % is WHERE the 13.3 GB of tables were allocated: recamd.ops.place_table_arena.
 template <int LPR, int IDS_F32>
-__global__ __launch_bounds__(256) void gather_uniform_kernel(
+__global__ __launch_bounds__(256, 4) void gather_uniform_kernel(
     TableSet ts, const void* __restrict__ ids, int64_t ids_stride, int F, int64_t R,
     float* __restrict__ out, int64_t out_stride, int* __restrict__ oob) {
   constexpr int D = LPR * 4;
@@ -110,7 +118,11 @@ __global__ __launch_bounds__(256) void gather_uniform_kernel(
       const int j = (it0 + u) * RPI + sub;
       const uint64_t s = shfl_u64(src, j);
       d[u] = shfl_u64(reinterpret_cast<uint64_t>(dst), j);
+#if REC_GATHER_LOAD_NT
+      u32x4 t = __builtin_nontemporal_load(reinterpret_cast<gsrc_t>((s & ~(uint64_t)1) + col * 4));
+#else
       u32x4 t = *reinterpret_cast<gsrc_t>((s & ~(uint64_t)1) + col * 4);
+#endif
       // bitwise mask (not a select, not a multiply): keeps the load unconditional and copies
       // inf/nan payloads bit-exactly; bit 0 set -> all-zero row
       const uint32_t keep = (uint32_t)(s & 1) - 1u;

@@ -74,6 +74,52 @@ class TableGroup:
         return len(self.tables)
 
 
+def place_table_arena(F: int, V: int, D: int, device, candidates: int = 4, probe_batch: int = 65536, probe_launches: int = 12,
+                      seed: int = 0):
+    """(F, V, D) fp32 arena for F embedding tables, PLACED BY MEASUREMENT.
+
+    The rate at which random rows of a multi-GB arena can be read depends on which physical memory the allocation
+    received — same kernel, same ids, same output buffer: 307-329 us for the BASELINE configs[1] gather on one box, stable
+    per allocation, different again after a free + re-allocation at the same virtual address
+    (tools/exp/arena_lottery.py, profiles/r02c_arena_lottery.txt).  Tables are allocated once and read for the life of the
+    model, and 288 GB of HBM leave room to choose: `candidates` arenas are allocated side by side (all alive, so they are
+    distinct memory), the materialised gather is timed on each with the same random ids, the fastest is kept and the rest
+    are freed.  Returns (arena, info) with the probe times of every candidate — callers report them (bench.py does).
+    candidates <= 1: one plain allocation, no probe."""
+    dev = torch.device(device)
+    if candidates <= 1:
+        return torch.empty((F, V, D), dtype=torch.float32, device=dev), {"candidates": 1}
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    Bp = int(probe_batch)
+    ids = [torch.randint(0, V, (Bp, F), device=dev, dtype=torch.int32, generator=gen) for _ in range(4)]
+    out = torch.empty((Bp, F * D), dtype=torch.float32, device=dev)
+    arenas, times = [], []
+    for _ in range(candidates):
+        try:
+            a = torch.empty((F, V, D), dtype=torch.float32, device=dev)
+        except torch.OutOfMemoryError:
+            break
+        a.zero_()                                   # touch every page: the probe must see the final mapping
+        arenas.append(a)
+    for a in arenas:
+        g = TableGroup([a[f] for f in range(F)])
+        for i in range(4):
+            gather_concat(g, ids[i % 4], out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(probe_launches):
+            gather_concat(g, ids[i % 4], out=out)
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) / probe_launches * 1e3)
+    best = min(range(len(arenas)), key=lambda i: times[i])
+    arena = arenas[best]
+    del arenas, a, g
+    torch.cuda.empty_cache()
+    return arena, {"candidates": len(times), "probe": "rec_gather_concat_f32, %d x %d uniform ids" % (Bp, F),
+                   "probe_us": [round(t, 1) for t in times], "chosen": best}
+
+
 def new_oob_flag(device) -> torch.Tensor:
     return torch.zeros(1, dtype=torch.int32, device=device)
 

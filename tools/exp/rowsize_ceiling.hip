@@ -7,9 +7,12 @@
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1)))* gsrc_t;
 
-template <int ROWB, int U, int NT>
+typedef u32x4 __attribute__((address_space(1)))* gdst_t;
+// STORE: 0 = read only; 1 = every row is also written to out + r * ROWB with nontemporal stores (the materialised gather's
+// traffic pattern: random rows in, one sequential stream out; with ids[r] = r it is a plain copy)
+template <int ROWB, int U, int NT, int STORE = 0>
 __global__ __launch_bounds__(256) void k_rows(const char* __restrict__ table, const int* __restrict__ ids, int64_t R,
-                                              uint32_t* sink) {
+                                              uint32_t* sink, char* __restrict__ out = nullptr) {
   constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -26,8 +29,16 @@ __global__ __launch_bounds__(256) void k_rows(const char* __restrict__ table, co
       gsrc_t p = (gsrc_t)(uintptr_t)(table + (int64_t)id * ROWB + col * 16);
       v[u] = NT ? __builtin_nontemporal_load(p) : *p;
     }
+    if (STORE) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc ^= v[u];
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * RPI + sub;
+        if (r < R) __builtin_nontemporal_store(v[u], (gdst_t)(uintptr_t)(out + r * ROWB + col * 16));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
   }
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
 }
@@ -35,6 +46,13 @@ __global__ __launch_bounds__(256) void k_rows(const char* __restrict__ table, co
 template <int ROWB, int U, int NT>
 static int go(const void* table, const int* ids, int64_t R, uint32_t* sink, int blocks, hipStream_t st) {
   hipLaunchKernelGGL((k_rows<ROWB, U, NT>), dim3(blocks), dim3(256), 0, st, (const char*)table, ids, R, sink);
+  return (int)hipGetLastError();
+}
+
+extern "C" int run_store(int nt, const void* table, const int* ids, int64_t R, uint32_t* sink, void* out, int blocks,
+                         hipStream_t st) {
+  if (nt) hipLaunchKernelGGL((k_rows<512, 16, 1, 1>), dim3(blocks), dim3(256), 0, st, (const char*)table, ids, R, sink, (char*)out);
+  else hipLaunchKernelGGL((k_rows<512, 16, 0, 1>), dim3(blocks), dim3(256), 0, st, (const char*)table, ids, R, sink, (char*)out);
   return (int)hipGetLastError();
 }
 
