@@ -113,10 +113,23 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
     gen = torch.Generator(device=dev).manual_seed(0)
     sharded = None
     placed = None
+    # ids, dense and result buffers are allocated BEFORE the tables: buffers that land in memory recycled from the freed
+    # arena candidates ran the gather 2 % slower (tools/exp/arena_drift.py)
+    ids = make_ids(torch, dev, a, B, F, V, rank)
+    dense = torch.rand((B, D), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    # (B, 479) result with a 480-float (16-B aligned) row stride, as recamd.ops allocates it
+    out_fused = torch.empty((B, (P + D + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P + D]
+    out_gather = torch.empty((B, F * D), dtype=torch.float32, device=dev)
     if a.placement == "replicated":
         # the arena is placed by measurement (recamd.ops.place_table_arena): which physical memory an allocation gets
         # changes the random-row read rate by up to 7 % on one box; every candidate's probe time is reported
-        arena, placed = ops.place_table_arena(F, V, D, dev, candidates=a.arena_candidates, probe_batch=B)
+        if fused:
+            probe = lambda g, i: ops.gather_pairwise_dot(g, ids[i % NB], dense, out=out_fused)  # noqa: E731
+        else:
+            probe = lambda g, i: ops.gather_concat(g, ids[i % NB], out=out_gather)  # noqa: E731
+        arena, placed = ops.place_table_arena(F, V, D, dev, candidates=a.arena_candidates, probe=probe,
+                                              probe_name="this workload's step (%s)" % ("rec_gather_pairwise_dot_f32" if fused
+                                                                                       else "rec_gather_concat_f32"))
         arena.uniform_(-0.05, 0.05, generator=gen)  # keras 'random_uniform' (dlrm/model.py:34)
         group = ops.TableGroup([arena[f] for f in range(F)])
     else:
@@ -126,11 +139,6 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
         arena.uniform_(-0.05, 0.05, generator=gen)
         sharded = ShardedTables([arena[f] for f in range(F)], [V] * F, rank, world)
         group = None
-    ids = make_ids(torch, dev, a, B, F, V, rank)
-    dense = torch.rand((B, D), device=dev, generator=gen)
-    # (B, 479) result with a 480-float (16-B aligned) row stride, as recamd.ops allocates it
-    out_fused = torch.empty((B, (P + D + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :P + D]
-    out_gather = torch.empty((B, F * D), dtype=torch.float32, device=dev)
 
     def step_fused(i):
         if sharded is None:
