@@ -136,3 +136,29 @@ def test_gather_ring_kernel_bit_exact(dev, B, F):
     out2 = ops.gather_concat(g, torch.from_numpy(ids2).to(dev), oob_flag=flag2).cpu().numpy()
     assert np.array_equal(out2.view(np.uint32), ref.gather_concat(tables, ids2).view(np.uint32))
     assert int(flag2.item()) == 0
+
+
+def test_place_table_arena_reports_every_candidate(dev):
+    """ops.place_table_arena: N candidate arenas probed with the caller's kernel, the fastest kept, every probe time
+    reported; candidates = 1 is a plain allocation without a probe"""
+    from recamd import ops
+    F, V, D, B = 3, 5000, 32, 512
+    ids = torch.randint(0, V, (B, F), device=dev, dtype=torch.int32)
+    out = torch.empty((B, F * D), device=dev)
+    calls = []
+
+    def probe(g, i):
+        calls.append(i)
+        ops.gather_concat(g, ids, out=out)
+    arena, info = ops.place_table_arena(F, V, D, dev, candidates=3, probe=probe, probe_launches=4, probe_name="test")
+    assert tuple(arena.shape) == (F, V, D) and arena.is_contiguous() and arena.dtype == torch.float32
+    assert info["candidates"] == 3 and len(info["probe_us"]) == 3 and 0 <= info["chosen"] < 3 and info["probe"] == "test"
+    assert all(t > 0 for t in info["probe_us"]) and calls
+    arena.uniform_(-1, 1)
+    got = ops.gather_concat(ops.TableGroup([arena[f] for f in range(F)]), ids)
+    exp = torch.cat([arena[f][ids[:, f].long()] for f in range(F)], dim=1)
+    assert torch.equal(got, exp)
+    plain, info1 = ops.place_table_arena(F, V, D, dev, candidates=1)
+    assert tuple(plain.shape) == (F, V, D) and info1 == {"candidates": 1}
+    dflt, info2 = ops.place_table_arena(2, 1000, 16, dev, candidates=2, probe_launches=2)   # default probe: the gather
+    assert tuple(dflt.shape) == (2, 1000, 16) and len(info2["probe_us"]) == 2
