@@ -282,7 +282,7 @@ def train_step(kind, W, opt, inputs, y, l2, **kw):
     opt.apply(W, {k: g for k, g in grads.items() if g is not None})
     for k, v in new_moving.items():
         W[k] = v.numpy()
-    return p.detach().numpy(), float(loss), float(reg)
+    return p.detach().numpy(), float(loss.detach()), float(reg.detach()) if hasattr(reg, "detach") else float(reg)
 
 
 def gradients(kind, W, inputs, y, **kw):
@@ -291,7 +291,7 @@ def gradients(kind, W, inputs, y, **kw):
     p, own_loss = _forward(kind, P, inputs, True, {}, kw)
     loss = own_loss if own_loss is not None else keras_bce(p, T(y).reshape(-1))
     loss.backward()
-    return {k: v.grad.numpy() for k, v in P.items() if v.requires_grad and v.grad is not None}, float(loss)
+    return {k: v.grad.numpy() for k, v in P.items() if v.requires_grad and v.grad is not None}, float(loss.detach())
 
 
 def predict(kind, W, inputs, **kw):
