@@ -249,7 +249,58 @@ def dropout_mask(n, rate, seed):
     return r >= np.uint64(thresh)
 
 
+def dense_stack(x, P, prefix, activation="relu"):
+    i = 0
+    while f"{prefix}/dense_{i}/kernel" in P:
+        x = act(x @ P[f"{prefix}/dense_{i}/kernel"] + P[f"{prefix}/dense_{i}/bias"], activation)
+        i += 1
+    return x
+
+
+def wide_deep_forward(P, dense_in, ids, activation="relu"):
+    """src/ctr/wide_deep/model.py:66-79"""
+    d = T(dense_in)
+    x = torch.cat([gather_concat(P, np.asarray(ids)), d], dim=-1)
+    wide = d @ P["linear/dense/kernel"] + P["linear/dense/bias"]
+    deep = dense_stack(x, P, "dnn_network", activation) @ P["final_dense/kernel"] + P["final_dense/bias"]
+    return torch.sigmoid(0.5 * wide + 0.5 * deep).reshape(-1)
+
+
+def deep_crossing_forward(P, ids):
+    """src/ctr/deep_crossing/model.py:42-51 with the residual unit of src/ctr/layers/modules.py:29-34"""
+    r = gather_concat(P, np.asarray(ids))
+    i = 0
+    while f"res_{i}/layer1/kernel" in P:
+        h = torch.relu(r @ P[f"res_{i}/layer1/kernel"] + P[f"res_{i}/layer1/bias"]) @ P[f"res_{i}/layer2/kernel"] \
+            + P[f"res_{i}/layer2/bias"]
+        r = torch.relu(h + r)
+        i += 1
+    return torch.sigmoid(r @ P["dense/kernel"] + P["dense/bias"]).reshape(-1)
+
+
+def ncf_forward(P, user, pos, neg, activation="relu"):
+    """src/match/ncf/model.py:47-80 -> (logits (B, 1 + n), add_loss)"""
+    ue = _table(P, "user_embedding/embeddings", user)                 # (B, 1, dim)
+
+    def branch(items):                                                # (B, T, dim)
+        Tn = items.shape[1]
+        u = ue.expand(-1, Tn, -1)
+        gmf = torch.sigmoid(u * items)
+        mlp = dense_stack(torch.cat([u, items], dim=-1), P, "dnn", activation)
+        return (torch.cat([gmf, mlp], dim=-1) @ P["dense/kernel"] + P["dense/bias"])[..., 0]
+    pl = branch(_table(P, "item_embedding/embeddings", pos))
+    nl = branch(_table(P, "neg_item_embedding/embeddings", neg))
+    loss = torch.mean(-torch.log(torch.sigmoid(pl)) - torch.log(1 - torch.sigmoid(nl))) / 2
+    return torch.cat([pl, nl], dim=-1), loss
+
+
 def _forward(kind, P, inputs, training, new_moving, kw):
+    if kind == "wide_deep":
+        return wide_deep_forward(P, inputs[0], inputs[1]), None
+    if kind == "deep_crossing":
+        return deep_crossing_forward(P, inputs), None
+    if kind == "ncf":
+        return ncf_forward(P, inputs[0], inputs[1], inputs[2])
     if kind == "dlrm":
         return dlrm_forward(P, inputs[0], np.asarray(inputs[1]), kw.get("interaction", "dot"), training=training,
                             new_moving=new_moving), None

@@ -9,6 +9,7 @@ class Deep_Crossing(Model):
     def __init__(self, feature_columns, hidden_units, res_dropout=0., embed_reg=1e-6):
         super().__init__()
         self.sparse_feature_columns = feature_columns
+        self.embed_reg = embed_reg
         self.embed_layers = {
             'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
                 input_dim=feat['feat_num'], input_length=1, output_dim=feat['embed_dim'],

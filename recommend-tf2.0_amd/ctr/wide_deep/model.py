@@ -37,6 +37,7 @@ class WideDeep(Model):
     def __init__(self, feature_columns, hidden_units, activation='relu', dnn_dropout=0., embed_reg=1e-4):
         super().__init__()
         self.dense_feature_columns, self.sparse_feature_columns = feature_columns
+        self.embed_reg = embed_reg
         self.embed_layers = {
             'embed_' + str(i): self.track('embed_' + str(i), nn.Embedding(
                 input_dim=feat['feat_num'], input_length=1, output_dim=feat['embed_dim'],

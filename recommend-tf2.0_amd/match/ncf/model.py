@@ -17,6 +17,7 @@ class NCF(Model):
                  activation='relu', neg_num=10, embed_reg=1e-6, **kwargs):
         super().__init__()
         self.neg_num = neg_num
+        self.embed_reg = embed_reg
         emb = lambda fc: nn.Embedding(input_dim=fc['feat_num'], output_dim=fc['embed_dim'],  # noqa: E731
                                       embeddings_initializer='random_normal')
         self.user_embedding = self.track('user_embedding', emb(user_feature_columns))

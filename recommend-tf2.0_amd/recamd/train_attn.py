@@ -360,3 +360,125 @@ def sasrec_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, 
 
 TRAIN_FORWARDS.update({"FM": fm_train_forward, "AutoInt": autoint_train_forward, "DIN": din_train_forward,
                        "SASRec": sasrec_train_forward})
+
+
+# ---- zoo models that reuse the path: Wide&Deep, Deep&Crossing, NCF --------------------------------------
+def scale_fwd(tape: Tape, x: Var, c: float) -> Var:
+    y = Var(ops.axpby_act(x.v, x.v, c, 0.0, None))
+
+    def bwd():
+        x.acc(ops.axpby_act(y.g, y.g, c, 0.0, None))
+    tape.ops.append(bwd)
+    return y
+
+
+def concat_fwd(tape: Tape, parts: Sequence[Var]) -> Var:
+    """tf.concat(parts, axis=-1) of 2-D activations; every part receives its column slice of the gradient"""
+    y = Var(torch.cat([p.v for p in parts], dim=-1))
+    widths = [p.v.shape[1] for p in parts]
+
+    def bwd():
+        off = 0
+        for p, w in zip(parts, widths):
+            p.acc(y.g[:, off:off + w].contiguous())
+            off += w
+    tape.ops.append(bwd)
+    return y
+
+
+def mul_sigmoid_fwd(tape: Tape, a: Var, b: Var) -> Var:
+    """sigmoid(a * b), elementwise (NCF's GMF vector, src/match/ncf/model.py:53-54)"""
+    y = Var(ops.mul_act(a.v, b.v, 'sigmoid'))
+
+    def bwd():
+        g = y.g.contiguous().clone()
+        C.act_grad_f32(g.data_ptr(), g.stride(0), y.v.data_ptr(), y.v.stride(0), g.shape[0], g.shape[1],
+                       ops._act_id('sigmoid'), _s())
+        a.acc(ops.mul_act(g, b.v, None))
+        b.acc(ops.mul_act(g, a.v, None))
+    tape.ops.append(bwd)
+    return y
+
+
+def tile_rows_fwd(tape: Tape, u: Var, T: int) -> Var:
+    """tf.tile(u[:, None, :], [1, T, 1]) flattened to (B * T, dim); the backward sums the T copies — as a product with
+    T stacked identity matrices on the Dense kernel (0 / 1 weights: exact)"""
+    B, dim = u.v.shape
+    if T == 1:
+        return u
+    y = Var(u.v[:, None, :].expand(B, T, dim).reshape(B * T, dim).contiguous())
+
+    def bwd():
+        eye = torch.eye(dim, dtype=torch.float32, device=u.v.device).repeat(T, 1)        # (T * dim, dim)
+        u.acc(ops.dense(y.g.contiguous().view(B, T * dim), eye))
+    tape.ops.append(bwd)
+    return y
+
+
+def dense_stack_fwd(tape: Tape, layers, name: str, x: Var, dropout_rate: float = 0.0) -> Var:
+    """a BatchNorm-free Dense stack + Dropout (wide_deep DNN, match DNN)"""
+    for i, layer in enumerate(layers):
+        x = dense_fwd(tape, layer, f"{name}/dense_{i}", x)
+    return dropout_fwd(tape, x, dropout_rate)
+
+
+def wide_deep_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """src/ctr/wide_deep/model.py:66-79, training mode (trained by src/ctr/wide_deep/train.py)"""
+    from .train import gather_concat_fwd
+    dense_inputs, sparse_inputs = inputs
+    dense_inputs = nn.to_device_f32(dense_inputs, m.device)
+    ids = nn.to_device_ids(sparse_inputs, m.device)
+    emb = gather_concat_fwd(tape, state, ops.TableGroup(m._group.tables), _embed_names(ids.shape[1]), ids)     # :68-69
+    dv = Var(dense_inputs)
+    x = concat_fwd(tape, [emb, dv])                                                                          # :70
+    wide = dense_fwd(tape, m.linear.dense, "linear/dense", dv)                                               # :73
+    deep = dense_stack_fwd(tape, m.dnn_network.dnn_network, "dnn_network", x, getattr(m.dnn_network.dropout, "rate", 0.0))
+    deep = dense_fwd(tape, m.final_dense, "final_dense", deep)                                               # :75-76
+    return sigmoid_bce(tape, [scale_fwd(tape, wide, 0.5), scale_fwd(tape, deep, 0.5)], y_true, grad_scale)   # :78
+
+
+def deep_crossing_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """src/ctr/deep_crossing/model.py:42-51, training mode"""
+    from .train import gather_concat_fwd
+    ids = nn.to_device_ids(inputs, m.device)
+    r = gather_concat_fwd(tape, state, ops.TableGroup(m._group.tables), _embed_names(ids.shape[1]), ids)       # :44-45
+    for i, res in enumerate(m.res_network):                                                                  # :47-48
+        h = dense_fwd(tape, res.layer2, f"res_{i}/layer2", dense_fwd(tape, res.layer1, f"res_{i}/layer1", r))
+        r = add_act_fwd(tape, h, r, 'relu')                                          # src/ctr/layers/modules.py:33
+    r = dropout_fwd(tape, r, getattr(m.res_dropout, "rate", 0.0))
+    return sigmoid_bce(tape, [dense_fwd(tape, m.dense, "dense", r)], y_true, grad_scale)                      # :50
+
+
+def ncf_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, grad_scale: float = 1.0):
+    """src/match/ncf/model.py:47-80, training mode; the objective is the model's add_loss (:75-77).  Returns (logits, loss)."""
+    user_in, pos_in, neg_in = [nn.to_device_ids(t, m.device) for t in inputs]
+    user_in, pos_in, neg_in = [t if t.dtype == torch.int32 else t.to(torch.int32) for t in (user_in, pos_in, neg_in)]
+    B = user_in.shape[0]
+    n_neg = neg_in.shape[1]
+    user = _rows_fwd(tape, state, m.user_embedding.table, "user_embedding/embeddings", user_in)      # (B, dim)
+    pos = _rows_fwd(tape, state, m.item_embedding.table, "item_embedding/embeddings", pos_in)        # (B, dim)
+    neg = _rows_fwd(tape, state, m.neg_item_embedding.table, "neg_item_embedding/embeddings", neg_in)  # (B * n, dim)
+    rate = getattr(m.dnn.dropout, "rate", 0.0)
+
+    def branch(item: Var, T: int) -> Var:
+        u = tile_rows_fwd(tape, user, T)                                                               # :63
+        gmf = mul_sigmoid_fwd(tape, u, item)                                                           # :53-54
+        mlp = dense_stack_fwd(tape, m.dnn.dnn_network, "dnn", concat_fwd(tape, [u, item]), rate)       # :61-66
+        return dense_fwd(tape, m.dense, "dense", concat_fwd(tape, [gmf, mlp]))                         # :69-73, (B * T, 1)
+    pos_l = branch(pos, 1)
+    neg_l = view_fwd(tape, branch(neg, n_neg), (B, n_neg))
+    logits = concat_fwd(tape, [pos_l, neg_l])                                                          # :79
+    lg = logits.v
+    loss = ops.pairwise_rank_loss(lg)                                                                  # :75-77
+
+    def bwd_loss():
+        dl = torch.empty_like(lg)
+        C.pairwise_rank_loss_grad_f32(lg.data_ptr(), lg.stride(0), B, n_neg, float(grad_scale), dl.data_ptr(), dl.stride(0), _s())
+        logits.acc(dl)
+    tape.ops.append(bwd_loss)
+    m._logits = lg
+    return lg, loss
+
+
+TRAIN_FORWARDS.update({"WideDeep": wide_deep_train_forward, "Deep_Crossing": deep_crossing_train_forward,
+                       "NCF": ncf_train_forward})

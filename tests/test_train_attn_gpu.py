@@ -400,3 +400,39 @@ def test_sasrec_fit_without_labels(dev):
     after = trainer.evaluate([seq, pos, neg])[0]
     assert set(hist) == {"loss", "val_loss"} and len(hist["loss"]) == 4
     assert hist["loss"][-1] < hist["loss"][0] and after < before
+
+
+# ---- zoo models: Wide&Deep (src/ctr/wide_deep/train.py), Deep&Crossing, NCF (src/match/ncf/train.py) ----
+def test_wide_deep_and_deep_crossing_training_steps(dev):
+    from ctr.deep_crossing.model import Deep_Crossing
+    from ctr.wide_deep.model import WideDeep
+    from tests.test_models_gpu import randomize
+    rng = np.random.default_rng(50)
+    B, F, V, D, nd = 64, 4, 17, 8, 5
+    sparse = [{'feat': f'C{i}', 'feat_num': V + i, 'embed_dim': D} for i in range(F)]
+    dense = rng.random((B, nd)).astype(np.float32)
+    ids = np.stack([rng.integers(0, V + i, size=B) for i in range(F)], axis=1).astype(np.int32)
+    y = (rng.random(B) < 0.4).astype(np.float32)
+    m = WideDeep([[{'feat': f'I{i}'} for i in range(nd)], sparse], hidden_units=[24, 12], embed_reg=1e-4)
+    m([dense, ids])
+    randomize(m, rng, 0.3)
+    run_steps(m, "wide_deep", {}, [dense, ids], y)
+    m = Deep_Crossing(sparse, hidden_units=[16, 8], embed_reg=1e-4)
+    m(ids)
+    randomize(m, rng, 0.3)
+    run_steps(m, "deep_crossing", {}, ids, y)
+
+
+def test_ncf_training_step(dev):
+    """NCF's add_loss minimised by Adam (dropout 0 for the parity check; src/match/ncf/train.py uses the default 0.2)"""
+    from match.ncf.model import NCF
+    from tests.test_models_gpu import randomize
+    rng = np.random.default_rng(51)
+    B, V, dim, n_neg = 32, 25, 8, 6
+    m = NCF({'feat': 'user_id', 'feat_num': V, 'embed_dim': dim}, {'feat': 'item_id', 'feat_num': V, 'embed_dim': dim},
+            hidden_units=[16, 8], dropout=0.0, neg_num=n_neg, embed_reg=1e-4)
+    user, pos = rng.integers(0, V, size=(B, 1)).astype(np.int32), rng.integers(0, V, size=(B, 1)).astype(np.int32)
+    neg = rng.integers(0, V, size=(B, n_neg)).astype(np.int32)
+    m([user, pos, neg])
+    randomize(m, rng, 0.3)
+    run_steps(m, "ncf", {}, [user, pos, neg], None)
