@@ -60,7 +60,7 @@ class WideDeep(Model):
         # vector paths (a tight 3341-float stride halves the gather rate)
         x = torch.empty((B, (We + nd + 3) // 4 * 4), dtype=torch.float32, device=self.device)[:, :We + nd]
         ops.gather_concat(self._group, sparse_inputs, out=x)               # :68-69
-        x[:, We:] = dense_inputs
+        ops.copy_cols(dense_inputs, x[:, We:])                           # tf.concat part written at its column offset
         wide_out = self.linear(dense_inputs)                               # :73
         deep_out = self.final_dense(self.dnn_network(x))                   # :75-76
         return ops.axpby_act(wide_out, deep_out, 0.5, 0.5, 'sigmoid')      # :78
