@@ -453,6 +453,14 @@ int rec_gather_dot_scores_grad_f32(const float* seq, const float* table, float* 
 int rec_fm_onehot_grad_f32(const float* dense, int64_t dense_stride, int32_t n_dense, const int32_t* ids,
                            int64_t ids_stride, int32_t F, const int32_t* vocab, const float* V, int32_t k,
                            const float* dlogit, int64_t B, float* dw, float* dV, void* stream);
+/* Weight gradient of a Dense layer with a SMALL kernel and a LONG batch axis: out (K, N) = x^T dy for x (M, K), dy
+ * (M, N), N <= 256 and K <= 64 * (256 / N) — the rows are split over workgroups and the partials summed in a fixed order (deterministic),
+ * where rec_dense_f32 on the transposed operand would walk all M rows in one or two workgroups (the projections of
+ * src/ctr/layers/modules.py:255-269 and src/match/layers/modules.py:110-112 see M = batch x positions).
+ * workspace: rec_wgrad_small_workspace_bytes(M, K, N). */
+int64_t rec_wgrad_small_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int rec_wgrad_small_f32(const float* x, int64_t x_stride, const float* dy, int64_t dy_stride, int64_t M, int32_t K,
+                        int32_t N, float* out, void* workspace, void* stream);
 /* tf.keras.layers.Dropout(rate) in training mode: y[e] = keep(seed, e) ? x[e] / (1 - rate) : 0 with a counter-based
  * mask (splitmix64 of seed and the element index; TensorFlow's own stream cannot be reproduced — parity unpinned by
  * construction).  The backward pass is the same call on dy.  In place (y == x) allowed. */

@@ -698,6 +698,14 @@ PYBIND11_MODULE(_C, m) {
                                  P<float>(dw), P<float>(dV), P<void>(stream)),
           "rec_fm_onehot_grad_f32");
   });
+  m.def("wgrad_small_workspace_bytes", [](int64_t M, int K, int N) { return rec_wgrad_small_workspace_bytes(M, K, N); });
+  m.def("wgrad_small_f32", [](ptr_t x, int64_t xs, ptr_t dy, int64_t dys, int64_t M, int K, int N, ptr_t out, ptr_t ws,
+                              ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_wgrad_small_f32(P<const float>(x), xs, P<const float>(dy), dys, M, K, N, P<float>(out), P<void>(ws),
+                              P<void>(stream)),
+          "rec_wgrad_small_f32");
+  });
   m.def("dropout_f32", [](ptr_t x, int64_t n, float rate, uint64_t seed, ptr_t y, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_dropout_f32(P<const float>(x), n, rate, seed, P<float>(y), P<void>(stream)), "rec_dropout_f32");

@@ -15,6 +15,7 @@
 //   rec_pairwise_rank_loss_grad_f32      add_loss of SASRec / NCF (match/sasrec/model.py:93-95)
 //   rec_gather_dot_scores_grad_f32       logits[b, j] = table[ids[b, j]] . seq[b] backward (sasrec/model.py:88-91)
 //   rec_fm_onehot_grad_f32               classic FM in gather form (src/ctr/fm/model.py:34-53) backward
+//   rec_wgrad_small_f32                  dW = X^T dY for K, N <= 128 over a long batch axis (split over workgroups)
 //   rec_dropout_f32                      Dropout(rate), training mode: counter-based mask (seed, element index), the
 //                                        backward is the same call on dy
 #include <math.h>
@@ -32,132 +33,214 @@ constexpr float kNegMaskLogit = -4294967296.0f;   // float32(-2**32 + 1)
 // and the S-wide outputs (o_i or dq_i) are produced with lanes over columns reading the probability row from LDS.
 constexpr int kMaxKeysPerLane = 8;   // Nk <= 512
 
-template <bool GRAD>
-__global__ __launch_bounds__(256) void attn_row_kernel(const float* __restrict__ q, int64_t ldq,
-                                                       const float* __restrict__ k, int64_t ldk,
-                                                       const float* __restrict__ v, int64_t ldv,
-                                                       const float* __restrict__ row_mask, int64_t B, int Nq, int Nk,
-                                                       int H, int S, float scale, float* __restrict__ out, int64_t ldo,
-                                                       const float* __restrict__ dO, int64_t lddo,
-                                                       float* __restrict__ dq, int64_t lddq, float* __restrict__ Pws,
-                                                       float* __restrict__ dSws) {
+// STAGED: one workgroup per (sample, head) keeps that head's K and V in LDS (row stride S + 1: the lane-private dots read
+// one row per lane) and its waves walk the query rows — at SASRec's training shape (Nk = 200, S = 64) the unstaged form
+// pulled 150 KB of K / V rows through L2 for EVERY query row (5.1 ms per call); unstaged remains for heads whose K and V do
+// not fit (2 Nk (S + 1) floats + the per-wave rows <= 128 KiB).
+constexpr int kAttnWaves = 8;
+template <bool GRAD, bool STAGED>
+__global__ __launch_bounds__(STAGED ? kAttnWaves * 64 : 256) void attn_row_kernel(
+    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk_g, const float* __restrict__ v,
+    int64_t ldv_g, const float* __restrict__ row_mask, int64_t B, int Nq, int Nk, int H, int S, float scale,
+    float* __restrict__ out, int64_t ldo, const float* __restrict__ dO, int64_t lddo, float* __restrict__ dq, int64_t lddq,
+    float* __restrict__ Pws, float* __restrict__ dSws) {
   extern __shared__ float attn_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = STAGED ? kAttnWaves : 4;
   float* prow = attn_lds + (size_t)w * 2 * Nk;   // p_j
   float* grow = prow + Nk;                       // dS_j
-  const int64_t row = (int64_t)blockIdx.x * 4 + w;
-  if (row >= B * H * Nq) return;                 // wave-uniform; no block barrier below
-  const int i = (int)(row % Nq);
-  const int h = (int)((row / Nq) % H);
-  const int64_t b = row / ((int64_t)Nq * H);
-  const float* qi = q + (b * Nq + i) * ldq + h * S;
-  const float* kb = k + b * Nk * ldk + h * S;
-  const float* vb = v + b * Nk * ldv + h * S;
-  const bool masked = row_mask && row_mask[b * Nq + i] == 0.f;
-  float s[kMaxKeysPerLane], p[kMaxKeysPerLane];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < kMaxKeysPerLane; ++t) {
-    const int j = lane + 64 * t;
-    s[t] = -INFINITY;
-    if (j < Nk) {
-      float a = 0.f;
-      const float* kj = kb + (int64_t)j * ldk;
-      for (int c = 0; c < S; ++c) a = fmaf(qi[c], kj[c], a);
-      s[t] = masked ? kNegMaskLogit : a * scale;
+  int64_t b;
+  int h, i_first, i_step;
+  if (STAGED) {
+    b = blockIdx.x / H;
+    h = blockIdx.x % H;
+    i_first = w;
+    i_step = NW;
+  } else {
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= B * H * Nq) return;                 // wave-uniform; no block barrier on this path
+    i_first = (int)(row % Nq);
+    h = (int)((row / Nq) % H);
+    b = row / ((int64_t)Nq * H);
+    i_step = Nq;                                   // exactly one query row
+  }
+  const float* kg = k + b * Nk * ldk_g + h * S;
+  const float* vg = v + b * Nk * ldv_g + h * S;
+  const float* kb = kg;
+  const float* vb = vg;
+  int64_t ldk = ldk_g, ldv = ldv_g;
+  if (STAGED) {
+    float* Ks = attn_lds + (size_t)NW * 2 * Nk;
+    float* Vs = Ks + (size_t)Nk * (S + 1);
+    for (int e = threadIdx.x; e < Nk * S; e += NW * 64) {
+      const int j = e / S, c = e - j * S;
+      Ks[j * (S + 1) + c] = kg[(int64_t)j * ldk_g + c];
+      Vs[j * (S + 1) + c] = vg[(int64_t)j * ldv_g + c];
     }
-    mx = fmaxf(mx, s[t]);
+    __syncthreads();
+    kb = Ks;
+    vb = Vs;
+    ldk = ldv = S + 1;
   }
-  mx = wave_max(mx);
-  float sum = 0.f;
+  for (int i = i_first; i < Nq; i += i_step) {
+    const int64_t row = (b * H + h) * Nq + i;
+    const float* qi = q + (b * Nq + i) * ldq + h * S;
+    const bool masked = row_mask && row_mask[b * Nq + i] == 0.f;
+    float s[kMaxKeysPerLane], p[kMaxKeysPerLane];
+    float mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < kMaxKeysPerLane; ++t) {
-    p[t] = (lane + 64 * t < Nk) ? expf(s[t] - mx) : 0.f;
-    sum += p[t];
-  }
-  sum = wave_sum(sum);
-  const float inv = 1.f / sum;
+    for (int t = 0; t < kMaxKeysPerLane; ++t) {
+      const int j = lane + 64 * t;
+      s[t] = -INFINITY;
+      if (j < Nk) {
+        float a = 0.f;
+        const float* kj = kb + (int64_t)j * ldk;
+        for (int c = 0; c < S; ++c) a = fmaf(qi[c], kj[c], a);
+        s[t] = masked ? kNegMaskLogit : a * scale;
+      }
+      mx = fmaxf(mx, s[t]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < kMaxKeysPerLane; ++t) p[t] *= inv;
-  if (!GRAD) {
+    for (int t = 0; t < kMaxKeysPerLane; ++t) {
+      p[t] = (lane + 64 * t < Nk) ? expf(s[t] - mx) : 0.f;
+      sum += p[t];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
 #pragma unroll
-    for (int t = 0; t < kMaxKeysPerLane; ++t)
-      if (lane + 64 * t < Nk) prow[lane + 64 * t] = p[t];
+    for (int t = 0; t < kMaxKeysPerLane; ++t) p[t] *= inv;
+    if (!GRAD) {
+#pragma unroll
+      for (int t = 0; t < kMaxKeysPerLane; ++t)
+        if (lane + 64 * t < Nk) prow[lane + 64 * t] = p[t];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float* oi = out + (b * Nq + i) * ldo + h * S;
+      for (int c = lane; c < S; c += 64) {
+        float a = 0.f;
+        for (int j = 0; j < Nk; ++j) a = fmaf(prow[j], vb[(int64_t)j * ldv + c], a);
+        oi[c] = a;
+      }
+      __builtin_amdgcn_wave_barrier();             // the next row overwrites prow
+      continue;
+    }
+    const float* doi = dO + (b * Nq + i) * lddo + h * S;
+    float dp[kMaxKeysPerLane];
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < kMaxKeysPerLane; ++t) {
+      const int j = lane + 64 * t;
+      dp[t] = 0.f;
+      if (j < Nk) {
+        float a = 0.f;
+        const float* vj = vb + (int64_t)j * ldv;
+        for (int c = 0; c < S; ++c) a = fmaf(doi[c], vj[c], a);
+        dp[t] = a;
+      }
+      delta = fmaf(p[t], dp[t], delta);
+    }
+    delta = wave_sum(delta);
+    float* Pw = Pws + row * Nk;
+    float* Gw = dSws + row * Nk;
+#pragma unroll
+    for (int t = 0; t < kMaxKeysPerLane; ++t) {
+      const int j = lane + 64 * t;
+      if (j < Nk) {
+        // a masked query row had every logit REPLACED by a constant (tf.where): no gradient reaches q_i or the keys
+        const float g = masked ? 0.f : p[t] * (dp[t] - delta) * scale;
+        Pw[j] = p[t];
+        Gw[j] = g;
+        grow[j] = g;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float* oi = out + (b * Nq + i) * ldo + h * S;
+    float* dqi = dq + (b * Nq + i) * lddq + h * S;
     for (int c = lane; c < S; c += 64) {
       float a = 0.f;
-      for (int j = 0; j < Nk; ++j) a = fmaf(prow[j], vb[(int64_t)j * ldv + c], a);
-      oi[c] = a;
+      for (int j = 0; j < Nk; ++j) a = fmaf(grow[j], kb[(int64_t)j * ldk + c], a);
+      dqi[c] = a;
     }
-    return;
-  }
-  const float* doi = dO + (b * Nq + i) * lddo + h * S;
-  float dp[kMaxKeysPerLane];
-  float delta = 0.f;
-#pragma unroll
-  for (int t = 0; t < kMaxKeysPerLane; ++t) {
-    const int j = lane + 64 * t;
-    dp[t] = 0.f;
-    if (j < Nk) {
-      float a = 0.f;
-      const float* vj = vb + (int64_t)j * ldv;
-      for (int c = 0; c < S; ++c) a = fmaf(doi[c], vj[c], a);
-      dp[t] = a;
-    }
-    delta = fmaf(p[t], dp[t], delta);
-  }
-  delta = wave_sum(delta);
-  float* Pw = Pws + row * Nk;
-  float* Gw = dSws + row * Nk;
-#pragma unroll
-  for (int t = 0; t < kMaxKeysPerLane; ++t) {
-    const int j = lane + 64 * t;
-    if (j < Nk) {
-      // a masked query row had every logit REPLACED by a constant (tf.where): no gradient reaches q_i or the keys
-      const float g = masked ? 0.f : p[t] * (dp[t] - delta) * scale;
-      Pw[j] = p[t];
-      Gw[j] = g;
-      grow[j] = g;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float* dqi = dq + (b * Nq + i) * lddq + h * S;
-  for (int c = lane; c < S; c += 64) {
-    float a = 0.f;
-    for (int j = 0; j < Nk; ++j) a = fmaf(grow[j], kb[(int64_t)j * ldk + c], a);
-    dqi[c] = a;
+    __builtin_amdgcn_wave_barrier();               // the next row overwrites grow
   }
 }
 
-// dK_j = sum_i dS_ij q_i (scale already inside dS), dV_j = sum_i P_ij dO_i: one wave per (b, h, j), lanes over columns
-__global__ __launch_bounds__(256) void attn_kv_grad_kernel(const float* __restrict__ q, int64_t ldq,
-                                                           const float* __restrict__ dO, int64_t lddo, int64_t B, int Nq,
-                                                           int Nk, int H, int S, const float* __restrict__ Pws,
-                                                           const float* __restrict__ dSws, float* __restrict__ dk,
-                                                           int64_t lddk, float* __restrict__ dv, int64_t lddv) {
+// dK_j = sum_i dS_ij q_i (scale already inside dS), dV_j = sum_i P_ij dO_i: lanes over columns.  STAGED: one workgroup per
+// (sample, head) with that head's Q and dO in LDS, its waves walk the key rows; otherwise one wave per (b, h, j).
+template <bool STAGED>
+__global__ __launch_bounds__(STAGED ? kAttnWaves * 64 : 256) void attn_kv_grad_kernel(
+    const float* __restrict__ q, int64_t ldq_g, const float* __restrict__ dO, int64_t lddo_g, int64_t B, int Nq, int Nk, int H,
+    int S, const float* __restrict__ Pws, const float* __restrict__ dSws, float* __restrict__ dk, int64_t lddk,
+    float* __restrict__ dv, int64_t lddv) {
+  extern __shared__ float attn_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + w;
-  if (row >= B * H * Nk) return;
-  const int j = (int)(row % Nk);
-  const int h = (int)((row / Nk) % H);
-  const int64_t b = row / ((int64_t)Nk * H);
-  const float* Pb = Pws + ((b * H + h) * Nq) * (int64_t)Nk + j;
-  const float* Gb = dSws + ((b * H + h) * Nq) * (int64_t)Nk + j;
-  const float* qb = q + b * Nq * ldq + h * S;
-  const float* dob = dO + b * Nq * lddo + h * S;
-  for (int c = lane; c < S; c += 64) {
-    float ak = 0.f, av = 0.f;
-    for (int i = 0; i < Nq; ++i) {
-      ak = fmaf(Gb[(int64_t)i * Nk], qb[(int64_t)i * ldq + c], ak);
-      av = fmaf(Pb[(int64_t)i * Nk], dob[(int64_t)i * lddo + c], av);
+  constexpr int NW = STAGED ? kAttnWaves : 4;
+  int64_t b;
+  int h, j_first, j_step;
+  if (STAGED) {
+    b = blockIdx.x / H;
+    h = blockIdx.x % H;
+    j_first = w;
+    j_step = NW;
+  } else {
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= B * H * Nk) return;
+    j_first = (int)(row % Nk);
+    h = (int)((row / Nk) % H);
+    b = row / ((int64_t)Nk * H);
+    j_step = Nk;
+  }
+  const float* qg = q + b * Nq * ldq_g + h * S;
+  const float* dog = dO + b * Nq * lddo_g + h * S;
+  const float* qb = qg;
+  const float* dob = dog;
+  int64_t ldq = ldq_g, lddo = lddo_g;
+  if (STAGED) {
+    float* Qs = attn_lds;
+    float* Ds = Qs + (size_t)Nq * S;
+    for (int e = threadIdx.x; e < Nq * S; e += NW * 64) {
+      const int i = e / S, c = e - i * S;
+      Qs[e] = qg[(int64_t)i * ldq_g + c];
+      Ds[e] = dog[(int64_t)i * lddo_g + c];
     }
-    dk[(b * Nk + j) * lddk + h * S + c] = ak;
-    dv[(b * Nk + j) * lddv + h * S + c] = av;
+    __syncthreads();
+    qb = Qs;
+    dob = Ds;
+    ldq = lddo = S;
+  }
+  // STAGED: column j of P and dS (stride Nk in the workspace) is gathered into a wave-private LDS line first — read in the
+  // accumulation loop straight from the workspace, every term waited for its own L2 round trip (1.8 ms per call at
+  // SASRec's shape)
+  float* pcol = attn_lds + (size_t)2 * Nq * S + (size_t)w * 2 * Nq;
+  float* gcol = pcol + Nq;
+  for (int j = j_first; j < Nk; j += j_step) {
+    const float* Pb = Pws + ((b * H + h) * Nq) * (int64_t)Nk + j;
+    const float* Gb = dSws + ((b * H + h) * Nq) * (int64_t)Nk + j;
+    if (STAGED) {
+      for (int i = lane; i < Nq; i += 64) {
+        pcol[i] = Pb[(int64_t)i * Nk];
+        gcol[i] = Gb[(int64_t)i * Nk];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    for (int c = lane; c < S; c += 64) {
+      float ak = 0.f, av = 0.f;
+      for (int i = 0; i < Nq; ++i) {
+        const float g = STAGED ? gcol[i] : Gb[(int64_t)i * Nk];
+        const float pp = STAGED ? pcol[i] : Pb[(int64_t)i * Nk];
+        ak = fmaf(g, qb[(int64_t)i * ldq + c], ak);
+        av = fmaf(pp, dob[(int64_t)i * lddo + c], av);
+      }
+      dk[(b * Nk + j) * lddk + h * S + c] = ak;
+      dv[(b * Nk + j) * lddv + h * S + c] = av;
+    }
+    if (STAGED) __builtin_amdgcn_wave_barrier();   // the next key row overwrites the lines
   }
 }
 
@@ -444,6 +527,58 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   y[i] = r >= thresh ? x[i] * keep_scale : 0.f;
 }
 
+// ---- dW = X^T dY for a SMALL output and a LONG reduction -----------------------------------------------------------------
+// The Dense backward of the attention-shaped models multiplies (K x M) by (M x N) with K, N <= 128 and M = batch x
+// positions (1e5 rows): one or two output tiles for the GEMM kernels, i.e. ONE workgroup walking the whole reduction
+// (16 ms per call at AutoInt's configs[2] shape — 96 % of its training step).  Here the rows are split over workgroups:
+// each stages 32-row slabs of X and dY in LDS and the per-workgroup partials are summed in a fixed order in fp64
+// (deterministic).
+constexpr int kWgSpan = 256, kWgSlab = 32;    // rows per workgroup (1024: too few workgroups to hide the slab loads), rows per LDS slab (at most)
+constexpr int kWgLdsFloats = 12288;          // 48 KiB of slabs: wide layers take fewer rows per slab
+// thread t = (n = t % N, kg = t / N) owns outputs (k, n) for k = kg, kg + G, ..., G = 256 / N k-groups: per staged row ONE
+// dY read (conflict-free across the wave) feeds up to JMAX independent FMAs whose X operands are broadcast reads — the
+// first version (outputs p = t, t + 256, ... with the row loop innermost) had one dependent LDS round trip per FMA and ran
+// 0.9 ms per call at SASRec's shape.
+template <int JMAX>
+__global__ __launch_bounds__(256) void wgrad_small_partial_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                  const float* __restrict__ dy, int64_t ldy, int64_t M, int K,
+                                                                  int N, int slab, float* __restrict__ part) {
+  extern __shared__ float wg_lds[];
+  float* xs = wg_lds;                 // [slab][K]
+  float* ds = wg_lds + slab * K;      // [slab][N]
+  const int t = threadIdx.x;
+  const int G = 256 / N;              // N <= 256 (host-checked)
+  const int n = t % N, kg = t / N;
+  const bool active = kg < G;
+  const int64_t r_begin = (int64_t)blockIdx.x * kWgSpan;
+  const int64_t r_end = r_begin + kWgSpan < M ? r_begin + kWgSpan : M;
+  float acc[JMAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) acc[j] = 0.f;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += slab) {
+    const int rows = (int)(r_end - r0 < slab ? r_end - r0 : slab);
+    __syncthreads();
+    for (int e = t; e < rows * K; e += 256) xs[e] = x[(r0 + e / K) * ldx + e % K];
+    for (int e = t; e < rows * N; e += 256) ds[e] = dy[(r0 + e / N) * ldy + e % N];
+    __syncthreads();
+    if (active) {
+      for (int r = 0; r < rows; ++r) {
+        const float d = ds[r * N + n];
+        const float* xr = xs + r * K + kg;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+          if (kg + j * G < K) acc[j] = fmaf(xr[j * G], d, acc[j]);
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int k = kg + j * G;
+      if (k < K) part[(int64_t)blockIdx.x * K * N + (int64_t)k * N + n] = acc[j];
+    }
+  }
+}
 }  // namespace rec
 
 using namespace rec;
@@ -463,6 +598,15 @@ static int attn_check(const char* who, int64_t B, int Nq, int Nk, int H, int S) 
   return REC_OK;
 }
 
+// dynamic LDS above 64 KiB needs the attribute; staged forms are used when the head's operands fit 128 KiB
+constexpr size_t kAttnStageMax = 128 * 1024;
+template <typename K>
+static bool raise_lds(K kern, size_t lds) {
+  return lds <= 64 * 1024 ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+}
+static size_t attn_row_staged_lds(int Nk, int S) { return ((size_t)kAttnWaves * 2 * Nk + (size_t)2 * Nk * (S + 1)) * sizeof(float); }
+
 extern "C" int rec_attn_core_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                  const float* row_mask, int64_t B, int32_t Nq, int32_t Nk, int32_t H, int32_t S,
                                  float scale, float* out, int64_t ldo, void* stream) {
@@ -473,10 +617,17 @@ extern "C" int rec_attn_core_f32(const float* q, int64_t ldq, const float* k, in
                 "%s: row stride < H * S", who);
   if (B == 0) return REC_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)4 * 2 * Nk * sizeof(float);
-  hipLaunchKernelGGL((attn_row_kernel<false>), dim3(blocks_of(B * H * Nq, 4)), dim3(256), lds, st, q, ldq, k, ldk, v, ldv,
-                     row_mask, B, Nq, Nk, H, S, scale, out, ldo, (const float*)nullptr, (int64_t)0, (float*)nullptr,
-                     (int64_t)0, (float*)nullptr, (float*)nullptr);
+  const size_t slds = attn_row_staged_lds(Nk, S);
+  if (slds <= kAttnStageMax && B * H <= 0x7fffffffLL && raise_lds(attn_row_kernel<false, true>, slds)) {
+    hipLaunchKernelGGL((attn_row_kernel<false, true>), dim3((unsigned)(B * H)), dim3(kAttnWaves * 64), slds, st, q, ldq, k, ldk,
+                       v, ldv, row_mask, B, Nq, Nk, H, S, scale, out, ldo, (const float*)nullptr, (int64_t)0, (float*)nullptr,
+                       (int64_t)0, (float*)nullptr, (float*)nullptr);
+  } else {
+    const size_t lds = (size_t)4 * 2 * Nk * sizeof(float);
+    hipLaunchKernelGGL((attn_row_kernel<false, false>), dim3(blocks_of(B * H * Nq, 4)), dim3(256), lds, st, q, ldq, k, ldk, v,
+                       ldv, row_mask, B, Nq, Nk, H, S, scale, out, ldo, (const float*)nullptr, (int64_t)0, (float*)nullptr,
+                       (int64_t)0, (float*)nullptr, (float*)nullptr);
+  }
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }
@@ -495,12 +646,24 @@ extern "C" int rec_attn_core_grad_f32(const float* q, int64_t ldq, const float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* Pws = reinterpret_cast<float*>(workspace);
   float* Gws = Pws + B * H * (int64_t)Nq * Nk;
-  const size_t lds = (size_t)4 * 2 * Nk * sizeof(float);
-  hipLaunchKernelGGL((attn_row_kernel<true>), dim3(blocks_of(B * H * Nq, 4)), dim3(256), lds, st, q, ldq, k, ldk, v, ldv,
-                     row_mask, B, Nq, Nk, H, S, scale, (float*)nullptr, (int64_t)0, dout, lddo, dq, lddq, Pws, Gws);
+  const size_t slds = attn_row_staged_lds(Nk, S);
+  if (slds <= kAttnStageMax && B * H <= 0x7fffffffLL && raise_lds(attn_row_kernel<true, true>, slds)) {
+    hipLaunchKernelGGL((attn_row_kernel<true, true>), dim3((unsigned)(B * H)), dim3(kAttnWaves * 64), slds, st, q, ldq, k, ldk,
+                       v, ldv, row_mask, B, Nq, Nk, H, S, scale, (float*)nullptr, (int64_t)0, dout, lddo, dq, lddq, Pws, Gws);
+  } else {
+    const size_t lds = (size_t)4 * 2 * Nk * sizeof(float);
+    hipLaunchKernelGGL((attn_row_kernel<true, false>), dim3(blocks_of(B * H * Nq, 4)), dim3(256), lds, st, q, ldq, k, ldk, v,
+                       ldv, row_mask, B, Nq, Nk, H, S, scale, (float*)nullptr, (int64_t)0, dout, lddo, dq, lddq, Pws, Gws);
+  }
   REC_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(attn_kv_grad_kernel, dim3(blocks_of(B * H * Nk, 4)), dim3(256), 0, st, q, ldq, dout, lddo, B, Nq, Nk, H,
-                     S, (const float*)Pws, (const float*)Gws, dk, lddk, dv, lddv);
+  const size_t klds = ((size_t)2 * Nq * S + (size_t)kAttnWaves * 2 * Nq) * sizeof(float);
+  if (klds <= kAttnStageMax && B * H <= 0x7fffffffLL && raise_lds(attn_kv_grad_kernel<true>, klds)) {
+    hipLaunchKernelGGL((attn_kv_grad_kernel<true>), dim3((unsigned)(B * H)), dim3(kAttnWaves * 64), klds, st, q, ldq, dout, lddo,
+                       B, Nq, Nk, H, S, (const float*)Pws, (const float*)Gws, dk, lddk, dv, lddv);
+  } else {
+    hipLaunchKernelGGL((attn_kv_grad_kernel<false>), dim3(blocks_of(B * H * Nk, 4)), dim3(256), 0, st, q, ldq, dout, lddo, B, Nq,
+                       Nk, H, S, (const float*)Pws, (const float*)Gws, dk, lddk, dv, lddv);
+  }
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }
@@ -644,4 +807,42 @@ extern "C" int rec_dropout_f32(const float* x, int64_t n, float rate, uint64_t s
                      thresh, 1.f / (1.f - rate), seed, y);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
+}
+
+extern "C" int64_t rec_wgrad_small_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+  int64_t chunks = (M + kWgSpan - 1) / kWgSpan;
+  chunks = chunks > 0 ? chunks : 1;
+  // the partials, then the workspace of the deterministic column sum that finishes them
+  return chunks * (int64_t)K * N * (int64_t)sizeof(float) + rec_colsum_workspace_bytes(chunks, (int64_t)K * N);
+}
+
+extern "C" int rec_wgrad_small_f32(const float* x, int64_t x_stride, const float* dy, int64_t dy_stride, int64_t M, int32_t K,
+                                   int32_t N, float* out, void* workspace, void* stream) {
+  const char* who = "rec_wgrad_small_f32";
+  REC_CHECK_ARG(x && dy && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(M >= 1 && K >= 1 && N >= 1 && x_stride >= K && dy_stride >= N, REC_ESHAPE, "%s: bad shape", who);
+  REC_CHECK_ARG(N <= 256 && K + N <= kWgLdsFloats && (K + 256 / N - 1) / (256 / N) <= 64, REC_ENOTIMPL,
+                "%s: needs N <= 256 and at most 64 outputs per thread (K = %d, N = %d): use rec_dense_f32 on the transposed "
+                "operand", who, K, N);
+  int slab = kWgLdsFloats / (K + N);
+  slab = slab > kWgSlab ? kWgSlab : slab;
+  const int J = (K + 256 / N - 1) / (256 / N);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t chunks = (M + kWgSpan - 1) / kWgSpan;
+  REC_CHECK_ARG(chunks <= 0x7fffffffLL, REC_ESHAPE, "%s: too many rows", who);
+  float* part = reinterpret_cast<float*>(workspace);
+  const size_t lds = (size_t)slab * (K + N) * sizeof(float);
+  if (J <= 4)
+    hipLaunchKernelGGL(wgrad_small_partial_kernel<4>, dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, dy_stride, M,
+                       K, N, slab, part);
+  else if (J <= 16)
+    hipLaunchKernelGGL(wgrad_small_partial_kernel<16>, dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, dy_stride,
+                       M, K, N, slab, part);
+  else
+    hipLaunchKernelGGL(wgrad_small_partial_kernel<64>, dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, dy_stride,
+                       M, K, N, slab, part);
+  REC_CHECK_LAUNCH(who);
+  const int64_t P = (int64_t)K * N;
+  // out[p] = sum over the chunks, fixed order, fp64 across 256-chunk groups (rec_colsum_f32 over the (chunks, P) partials)
+  return rec_colsum_f32(part, P, nullptr, 0, nullptr, chunks, P, out, part + chunks * P, stream);
 }

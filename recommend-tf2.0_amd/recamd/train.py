@@ -50,6 +50,21 @@ def colsum(a: torch.Tensor, b: Optional[torch.Tensor] = None, row_w: Optional[to
     return out
 
 
+def weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dW = x^T dy for x (M, K), dy (M, N).  Small kernels under a long batch axis (the projections of the attention
+    models: M = batch x positions) take rec_wgrad_small_f32, which splits the rows over workgroups; everything else is the
+    forward GEMM on the transposed operand."""
+    M, K = x.shape
+    N = dy.shape[1]
+    if N <= 256 and K <= 64 * (256 // N) and K + N <= 384 and M >= 2048 and x.stride(1) == 1 and dy.stride(1) == 1:
+        out = torch.empty((K, N), dtype=torch.float32, device=x.device)
+        ws = _ws(C.wgrad_small_workspace_bytes(M, K, N), x.device)
+        C.wgrad_small_f32(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), M, K, N, out.data_ptr(), ws.data_ptr(), _s())
+        return out
+    xc = x if x.is_contiguous() else x.contiguous()
+    return ops.dense(transpose(xc), dy)
+
+
 def sum_squares(t: torch.Tensor) -> torch.Tensor:
     """sum(t^2) as a 1-element device tensor (regularisation losses)"""
     flat = t.reshape(-1)
@@ -116,8 +131,7 @@ def dense_fwd(tape: Tape, layer: nn.Dense, name: str, x: Var) -> Var:
                            ops._act_id(act), _s())
         if b is not None:
             tape.add_grad(name + "/bias", colsum(dy))
-        xc = xin if xin.is_contiguous() else xin.contiguous()
-        tape.add_grad(name + "/kernel", ops.dense(transpose(xc), dy))          # dW = X^T dY
+        tape.add_grad(name + "/kernel", weight_grad(xin, dy))                   # dW = X^T dY
         x.acc(ops.dense(dy, transpose(W)))                                      # dX = dY W^T
     tape.ops.append(bwd)
     if isinstance(layer_act, nn.PReLU):

@@ -16,7 +16,8 @@ import torch
 
 from . import nn, ops
 from ._lib import C
-from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, dense_fwd, sigmoid_bce, transpose)
+from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, dense_fwd, sigmoid_bce, transpose,
+                    weight_grad)
 
 
 # ---- small tape ops ----------------------------------------------------------------------------------------------
@@ -43,7 +44,7 @@ def matmul_act_fwd(tape: Tape, x: Var, W: torch.Tensor, gname: str, act) -> Var:
             dy = dy.clone()
             C.act_grad_f32(dy.data_ptr(), dy.stride(0), y.v.data_ptr(), y.v.stride(0), dy.shape[0], dy.shape[1],
                            ops._act_id(act), _s())
-        tape.add_grad(gname, ops.dense(transpose(x.v), dy))
+        tape.add_grad(gname, weight_grad(x.v, dy))
         x.acc(ops.dense(dy, transpose(W)))
     tape.ops.append(bwd)
     return y

@@ -436,3 +436,24 @@ def test_ncf_training_step(dev):
     m([user, pos, neg])
     randomize(m, rng, 0.3)
     run_steps(m, "ncf", {}, [user, pos, neg], None)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (2048, 16, 32), (5000, 64, 64), (3001, 128, 128), (40000, 39, 7), (2500, 1248, 1),
+                                   (2100, 5, 200), (3000, 64, 128)])
+def test_weight_grad_small_kernel(dev, M, K, N):
+    """rec_wgrad_small_f32 (rows split over workgroups, fixed-order fp64 finish) against x^T dy in fp64; and the
+    dispatcher's two paths agree"""
+    from recamd import train as tr
+    from recamd._lib import C
+    rng = np.random.default_rng(M + K)
+    x, dy = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(M, N)).astype(np.float32)
+    tx, tdy = G(x, dev), G(dy, dev)
+    out = torch.empty((K, N), device=dev)
+    ws = torch.empty(int(C.wgrad_small_workspace_bytes(M, K, N)), dtype=torch.uint8, device=dev)
+    C.wgrad_small_f32(tx.data_ptr(), tx.stride(0), tdy.data_ptr(), tdy.stride(0), M, K, N, out.data_ptr(), ws.data_ptr(), stream())
+    exp = x.astype(np.float64).T @ dy.astype(np.float64)
+    assert close(out.cpu().numpy(), exp, floor=float(np.sqrt(M)))          # sums of M products of O(1) operands
+    assert close(tr.weight_grad(tx, tdy).cpu().numpy(), exp, floor=float(np.sqrt(M)))
+    again = torch.empty_like(out)
+    C.wgrad_small_f32(tx.data_ptr(), tx.stride(0), tdy.data_ptr(), tdy.stride(0), M, K, N, again.data_ptr(), ws.data_ptr(), stream())
+    assert torch.equal(out, again)                                           # deterministic
