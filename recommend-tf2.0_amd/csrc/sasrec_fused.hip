@@ -31,6 +31,10 @@
 // wave assignment costs 6 %; the rest is bytes in flight: 16 waves x 8 KiB per CU is all the VGPR file gives at 128
 // registers per wave, and the LDS that could land more is full of weights.  (Dynamic sample -> wave assignment through an
 // LDS counter inside the workgroup was tried: 92.4 vs 92.0 us on the same box — the residual imbalance is between CUs.)
+// Second session: fewer waves with deeper landing buffers LOSE (tools/exp/sasrec_waves_ab.sh, same box, waves x loads per
+// buffer): 16 x 4 (128 KiB in flight per CU, shipped) 86.0 us; 12 x 6 (144 KiB) 93.4; 8 x 8 (128 KiB) 93.4; 8 x 12 (192 KiB)
+// 103.3; 8 x 16 (256 KiB) 105.0 — the number of waves that can overlap each other's serial phases matters more than the
+// bytes each keeps in flight.
 #include "common.h"
 
 namespace rec {
@@ -42,7 +46,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr bool kRowsNT = REC_SASREC_ROWS_NT != 0;   // streaming row loads: 94.0 -> 89.3 us at configs[4] (common.h row_load)
 
 constexpr int kD = 64;       // d_model
-constexpr int kWaves = 16;   // per workgroup
+#ifndef REC_SASREC_WAVES
+#define REC_SASREC_WAVES 16
+#endif
+constexpr int kWaves = REC_SASREC_WAVES;   // per workgroup (one workgroup per CU: the weights fill the LDS)
 #ifndef REC_SASREC_KU
 #define REC_SASREC_KU 4
 #endif
