@@ -18,6 +18,12 @@ Untimed: a device spin-up (>= 0.3 s of steps: clocks and TLBs settle; the first 
 `value` = units of all ranks / max-over-ranks wall time.  A second, separate pass brackets every launch with
 its own HIP events for the p10/p50/p90 in `launch_us`.
 
+Table placement: the time of both DLRM kernels depends on which physical memory the 13.3 GB of tables received (same
+box, same kernel: gather 307-329 us, fused 165-182 us by allocation; DESIGN.md section 5 'Placement').  By default the
+tables are placed by measurement (recamd.ops.place_table_arena): --arena-candidates N (default 6) arenas are allocated
+side by side, this workload's own step is timed on each, the fastest is kept; EVERY candidate's probe time is printed
+in config.table_placement.  --arena-candidates 1 = one plain allocation.
+
 Multi-GPU (driver: torch.distributed.run, one rank per GPU, RCCL): weak scaling, the same batch per GPU.
   --placement replicated (default): every GPU holds all tables (13.3 GB of 288 GB), as the reference's
       MirroredStrategy mirrors its variables (src/ctr/fm/train.py:43); the forward has no collective.
