@@ -399,7 +399,12 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ alpha, int act, int64_t B,
                                                                   int T, float* __restrict__ out, int* __restrict__ oob) {
-  constexpr int Dt = 64, d = NTAB * Dt, U = 2;
+  // batch depth (tools/exp/din_u_ab.sh, same box): U = 1 (94 VGPRs, five waves per SIMD, 120 KiB in flight per CU) and U = 2
+  // (120 VGPRs, four waves, 192 KiB) both run configs[3] in 64.3 us: neither the bytes in flight nor the wave count bound it
+#ifndef REC_DIN_U
+#define REC_DIN_U 2
+#endif
+  constexpr int Dt = 64, d = NTAB * Dt, U = REC_DIN_U;
   constexpr float kLog2e = 1.4426950408889634f;
   extern __shared__ int32_t din_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
