@@ -6,6 +6,8 @@
 #include <stdlib.h>
 
 #include "attention_ctr.h"
+#include <type_traits>
+
 #include "common.h"
 
 namespace rec {
@@ -477,7 +479,11 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
 #ifndef REC_DIN_NT
 #define REC_DIN_NT 0
 #endif
-  auto load_batch = [&](int i0, f32x4 (&kr)[U][NTAB]) {
+  // REC_DIN_NT = 2 (mixed; A/B: 64.5 vs 64.4 us — no gain, off): a batch in which EVERY lane group has its own slot is fetched with the streaming policy; the
+  // tail batch and the prefetches past the end, whose spare groups re-read the last slot, keep the default policy (that
+  // re-read must stay a cache hit).  The choice is wave-uniform.
+  auto load_batch_p = [&](int i0, f32x4 (&kr)[U][NTAB], auto nt_tag) {
+    constexpr bool NTV = decltype(nt_tag)::value;
 #pragma unroll
     for (int e = 0; e < U; ++e) {
       const int i = i0 + 4 * e + grp;
@@ -491,8 +497,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
         for (int tt = 0; tt < NTAB; ++tt) {
           const int32_t id = sid[t * NTAB + tt];
           const bool ok = (uint32_t)id < (uint32_t)tb.vocab[tt];
-          const f32x4 row = row_load<REC_DIN_NT != 0>(
-              reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
+          const f32x4 row = row_load<NTV>(reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
           kr[e][tt] = ok ? row : z4;
         }
       } else {
@@ -505,12 +510,21 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
       for (int tt = 0; tt < NTAB; ++tt) {
         const int32_t id = sid[t * NTAB + tt];
         const bool ok = (uint32_t)id < (uint32_t)tb.vocab[tt];
-        const f32x4 row = row_load<REC_DIN_NT != 0>(
-            reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
+        const f32x4 row = row_load<NTV>(reinterpret_cast<const f32x4*>(tb.base[tt] + (int64_t)(ok ? id : 0) * Dt + sub * 4));
         kr[e][tt] = ok ? row : z4;
       }
 #endif
     }
+  };
+  auto load_batch = [&](int i0, f32x4 (&kr)[U][NTAB]) {
+#if REC_DIN_NT == 2
+    if (i0 + 4 * U <= n) load_batch_p(i0, kr, std::true_type{});
+    else load_batch_p(i0, kr, std::false_type{});
+#elif REC_DIN_NT == 1
+    load_batch_p(i0, kr, std::true_type{});
+#else
+    load_batch_p(i0, kr, std::false_type{});
+#endif
   };
   float m = -INFINITY, l = 0.f;
   f32x4 acc[NTAB];
@@ -522,12 +536,11 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
 #pragma unroll
     for (int e = 0; e < U; ++e) {
       const int i = i0 + 4 * e + grp;
-      float dsum = 0.f;
+      // the tables' products are chained as packed FMAs first, ONE horizontal sum afterwards (was: one per table)
+      f32x4 pr = kr[e][0] * u[0];
 #pragma unroll
-      for (int tt = 0; tt < NTAB; ++tt) {
-        const f32x4 pr = kr[e][tt] * u[tt];
-        dsum += (pr.x + pr.y) + (pr.z + pr.w);
-      }
+      for (int tt = 1; tt < NTAB; ++tt) pr = __builtin_elementwise_fma(kr[e][tt], u[tt], pr);
+      float dsum = (pr.x + pr.y) + (pr.z + pr.w);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
       float sv = act_apply(dsum + c0, act, al);
