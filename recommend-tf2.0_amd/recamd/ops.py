@@ -9,6 +9,8 @@ from __future__ import annotations
 import weakref
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 
 from ._lib import C
