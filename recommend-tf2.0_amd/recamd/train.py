@@ -618,14 +618,18 @@ class Trainer:
     def _len(x):
         return len(x[0]) if isinstance(x, (list, tuple)) else len(x)
 
-    def reg_loss(self) -> float:
-        """sum of the l2 regularisation losses Keras adds to the reported loss: c * sum(w^2) per regularised weight"""
-        tot = 0.0
+    def reg_loss_device(self) -> torch.Tensor:
+        """sum of the l2 regularisation losses Keras adds to the reported loss — c * sum(w^2) per regularised weight — as a
+        1-element DEVICE tensor (no host synchronisation: fit() accumulates it on the device)"""
+        tot = torch.zeros(1, dtype=torch.float32, device=self.model.device)
         for name, w in named_weights(self.model).items():
             c = self.opt._l2_of(name)
             if c:
-                tot += c * float(sum_squares(w).item())
+                tot = ops.axpby_act(tot, sum_squares(w), 1.0, float(c), None)
         return tot
+
+    def reg_loss(self) -> float:
+        return float(self.reg_loss_device().item())
 
     def predict(self, x, batch_size: int = 4096) -> np.ndarray:
         n = self._len(x)
@@ -669,17 +673,19 @@ class Trainer:
             history.update(dict(val_loss=[], val_auc=[]) if has_y else dict(val_loss=[]))
         for epoch in range(epochs):
             order = np.random.default_rng(seed + epoch).permutation(n_tr) if shuffle else np.arange(n_tr)
-            loss_sum, preds, labels = 0.0, [], []
+            # the epoch's loss is accumulated ON THE DEVICE (one host synchronisation per epoch, not several per batch)
+            loss_sum, preds, labels = torch.zeros(1, dtype=torch.float32, device=self.model.device), [], []
             for lo in range(0, n_tr, batch_size):
                 idx = order[lo:lo + batch_size]
-                reg = self.reg_loss()          # Keras adds the regularisation losses of the weights the batch SAW
+                reg = self.reg_loss_device()   # Keras adds the regularisation losses of the weights the batch SAW
                 p, loss = train_step(self.model, self.opt, self.state, self._slice(xt, idx), yt_all[idx] if has_y else None,
                                      self.allreduce, self.world)
-                loss_sum += (float(loss.item()) + reg) * len(idx)
+                batch_loss = ops.axpby_act(loss.reshape(1), reg, 1.0, 1.0, None)
+                loss_sum = ops.axpby_act(loss_sum, batch_loss, 1.0, float(len(idx)), None)
                 if has_y:
                     preds.append(p.reshape(-1))
                     labels.append(yt_all[idx])
-            logs = {"loss": loss_sum / n_tr}
+            logs = {"loss": float(loss_sum.item()) / n_tr}
             if has_y:
                 lt = nn.to_device_f32(np.concatenate(labels), self.model.device)
                 logs["auc"] = float(ops.auc(lt, torch.cat(preds)).item())
