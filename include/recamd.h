@@ -461,6 +461,10 @@ int rec_fm_onehot_grad_f32(const float* dense, int64_t dense_stride, int32_t n_d
 int64_t rec_wgrad_small_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int rec_wgrad_small_f32(const float* x, int64_t x_stride, const float* dy, int64_t dy_stride, int64_t M, int32_t K,
                         int32_t N, float* out, void* workspace, void* stream);
+/* dp[i] = scale * d BCE_keras(y_i, p_i) / dp_i for a probability that is not itself a sigmoid output (ESMM's
+ * pCTCVR = pCTR * pCVR, src/ctr/esmm/model.py:44, trained with loss=["binary_crossentropy", "binary_crossentropy"],
+ * src/ctr/esmm/train.py:101); the clip of rec_binary_crossentropy_f32 zeroes the gradient outside [eps, 1 - eps]. */
+int rec_bce_prob_grad_f32(const float* y_true, const float* p, int64_t n, float scale, float* dp, void* stream);
 /* tf.keras.layers.Dropout(rate) in training mode: y[e] = keep(seed, e) ? x[e] / (1 - rate) : 0 with a counter-based
  * mask (splitmix64 of seed and the element index; TensorFlow's own stream cannot be reproduced — parity unpinned by
  * construction).  The backward pass is the same call on dy.  In place (y == x) allowed. */

@@ -134,13 +134,15 @@ def is_moving(k):
 
 
 class AdamOracle:
-    def __init__(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
-        self.lr, self.b1, self.b2, self.eps, self.t, self.m, self.v = lr, b1, b2, eps, 0, {}, {}
+    def __init__(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, decay=0.0):
+        self.lr, self.b1, self.b2, self.eps, self.t, self.m, self.v, self.decay = lr, b1, b2, eps, 0, {}, {}, decay
 
     def apply(self, W, grads):
-        """W: {name: fp64 ndarray} updated in place; grads include the regularisers' gradients"""
+        """W: {name: fp64 ndarray} updated in place; grads include the regularisers' gradients.  decay: the legacy Keras
+        schedule lr / (1 + decay * iterations) with `iterations` counted before this step (src/ctr/esmm/train.py:95)"""
+        lr = self.lr / (1.0 + self.decay * self.t)
         self.t += 1
-        lr_t = self.lr * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        lr_t = lr * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
         for k, g in grads.items():
             m = self.m.setdefault(k, np.zeros_like(W[k]))
             v = self.v.setdefault(k, np.zeros_like(W[k]))
@@ -294,6 +296,29 @@ def ncf_forward(P, user, pos, neg, activation="relu"):
     return torch.cat([pl, nl], dim=-1), loss
 
 
+def esmm_forward(P, inputs, user_keys, user_cols, item_keys, item_cols, activation="relu", training=True, new_moving=None):
+    """src/ctr/esmm/model.py:37-92 -> (pCTR, pCTCVR).  The shared DNNs' BatchNormalization layers are called once per
+    tower: in training mode the second call starts from the moving statistics the first one left (Keras updates them
+    call by call)."""
+    new_moving = {} if new_moving is None else new_moving
+    xs = [np.asarray(a, np.float64) for a in inputs]
+
+    def tower(head, un, uc, inum, ic):
+        Q = dict(P)
+        Q.update(new_moving)                                  # what the previous tower's calls left behind
+        ue = torch.cat([_table(P, f"embed_{k}/embeddings", uc[:, c]) for k, c in zip(user_keys, user_cols)], dim=-1)
+        ie = torch.cat([_table(P, f"embed_{k}/embeddings", ic[:, c]) for k, c in zip(item_keys, item_cols)], dim=-1)
+        uf = dnn(torch.cat([T(un), ue], dim=-1), Q, "user_dnn", n_dense(P, "user_dnn"), activation, training, new_moving)
+        itf = dnn(torch.cat([T(inum), ie], dim=-1), Q, "item_dnn", n_dense(P, "item_dnn"), activation, training, new_moving)
+        x = torch.cat([uf, itf], dim=-1)
+        x = bn_train(x, P, head + "/bn", new_moving) if training else bn_infer(x, P, head + "/bn")
+        x = torch.relu(x @ P[head + "/dense/kernel"] + P[head + "/dense/bias"])
+        return torch.sigmoid(x @ P[head + "/out/kernel"] + P[head + "/out/bias"]).reshape(-1)
+    ctr = tower("ctr_head", *xs[:4])
+    cvr = tower("cvr_head", *xs[4:])
+    return ctr, ctr * cvr
+
+
 def _forward(kind, P, inputs, training, new_moving, kw):
     if kind == "wide_deep":
         return wide_deep_forward(P, inputs[0], inputs[1]), None
@@ -325,7 +350,13 @@ def train_step(kind, W, opt, inputs, y, l2, **kw):
     loss = mean Keras BCE against y, or the model's add_loss for 'sasrec' (y = None, predictions = logits)."""
     P = {k: T(v, grad=not is_moving(k)) for k, v in W.items()}
     new_moving = {}
-    p, own_loss = _forward(kind, P, inputs, True, new_moving, kw)
+    if kind == "esmm":
+        ctr, ctcvr = esmm_forward(P, inputs, kw["user_keys"], kw["user_cols"], kw["item_keys"], kw["item_cols"], training=True,
+                                  new_moving=new_moving)
+        p = torch.stack([ctr, ctcvr])
+        own_loss = keras_bce(ctr, T(y[0]).reshape(-1)) + keras_bce(ctcvr, T(y[1]).reshape(-1))
+    else:
+        p, own_loss = _forward(kind, P, inputs, True, new_moving, kw)
     loss = own_loss if own_loss is not None else keras_bce(p, T(y).reshape(-1))
     reg = reg_loss(P, l2)
     (loss + reg).backward()

@@ -706,6 +706,11 @@ PYBIND11_MODULE(_C, m) {
                               P<void>(stream)),
           "rec_wgrad_small_f32");
   });
+  m.def("bce_prob_grad_f32", [](ptr_t y, ptr_t p, int64_t n, float scale, ptr_t dp, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_bce_prob_grad_f32(P<const float>(y), P<const float>(p), n, scale, P<float>(dp), P<void>(stream)),
+          "rec_bce_prob_grad_f32");
+  });
   m.def("dropout_f32", [](ptr_t x, int64_t n, float rate, uint64_t seed, ptr_t y, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_dropout_f32(P<const float>(x), n, rate, seed, P<float>(y), P<void>(stream)), "rec_dropout_f32");

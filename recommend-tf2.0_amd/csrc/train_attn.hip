@@ -579,6 +579,18 @@ __global__ __launch_bounds__(256) void wgrad_small_partial_kernel(const float* _
     }
   }
 }
+// ---- Keras binary cross-entropy on a PROBABILITY that is not a sigmoid output (ESMM's pCTCVR = pCTR * pCVR) ----------------
+// dL/dp_i = scale * [ -(y/(pc+e)) + (1-y)/(1-pc+e) ] * [e < p < 1-e], pc = clip(p, e, 1-e)
+__global__ __launch_bounds__(256) void bce_prob_grad_kernel(const float* __restrict__ y, const float* __restrict__ p, int64_t n,
+                                                            float scale, float* __restrict__ dp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float e = 1e-7f, pi = p[i], yi = y[i];
+  const float pc = fminf(fmaxf(pi, e), 1.f - e);
+  const float inside = (pi > e && pi < 1.f - e) ? 1.f : 0.f;
+  dp[i] = scale * inside * (-(yi / (pc + e)) + (1.f - yi) / (1.f - pc + e));
+}
+
 }  // namespace rec
 
 using namespace rec;
@@ -845,4 +857,15 @@ extern "C" int rec_wgrad_small_f32(const float* x, int64_t x_stride, const float
   const int64_t P = (int64_t)K * N;
   // out[p] = sum over the chunks, fixed order, fp64 across 256-chunk groups (rec_colsum_f32 over the (chunks, P) partials)
   return rec_colsum_f32(part, P, nullptr, 0, nullptr, chunks, P, out, part + chunks * P, stream);
+}
+
+extern "C" int rec_bce_prob_grad_f32(const float* y_true, const float* p, int64_t n, float scale, float* dp, void* stream) {
+  const char* who = "rec_bce_prob_grad_f32";
+  REC_CHECK_ARG(n >= 0, REC_ESHAPE, "%s: bad shape", who);
+  if (n == 0) return REC_OK;
+  REC_CHECK_ARG(y_true && p && dp, REC_EINVAL, "%s: NULL pointer", who);
+  hipLaunchKernelGGL(bce_prob_grad_kernel, dim3(blocks_of(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y_true, p,
+                     n, scale, dp);
+  REC_CHECK_LAUNCH(who);
+  return REC_OK;
 }

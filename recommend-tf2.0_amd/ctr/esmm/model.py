@@ -33,6 +33,7 @@ class ESMM(Model):
                  dropout=0., embed_reg=1e-4):
         super().__init__()
         self.cate_feature_columns = cate_feature_columns
+        self.embed_reg = embed_reg
         self.user_cate_feature_dict, self.item_cate_feature_dict = cate_feature_dict
         self.hidden_units = hidden_units
         self.embed_layers = {

@@ -362,8 +362,10 @@ class Adam:
     decayed) — the exact form touches every row of every table each step, 28 B per parameter."""
 
     def __init__(self, model: nn.Layer, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, l2: Optional[Dict[str, float]] = None,
-                 sparse_embeddings: bool = False):
-        self.model, self.lr, self.b1, self.b2, self.eps = model, learning_rate, beta_1, beta_2, epsilon
+                 sparse_embeddings: bool = False, decay: float = 0.0):
+        self.model, self.lr0, self.b1, self.b2, self.eps = model, learning_rate, beta_1, beta_2, epsilon
+        self.lr = learning_rate
+        self.decay = decay        # Adam(learning_rate, decay=...) of src/ctr/esmm/train.py:95: lr / (1 + decay * iterations)
         self.l2 = dict(l2 or {})
         self.sparse = sparse_embeddings
         self.step_no = 0
@@ -387,6 +389,7 @@ class Adam:
     def apply(self, grads: Dict[str, torch.Tensor], state: TrainState, sparse_ids=None):
         """grads: dense-parameter gradients by name; embedding gradients come from `state`.  sparse_ids: list of
         (names, ids (B,F) int32) for the lazy update."""
+        self.lr = self.lr0 / (1.0 + self.decay * self.step_no)      # `iterations` = steps taken so far
         self.step_no += 1
         weights = self.trainable()
         lazy = set()
@@ -528,7 +531,10 @@ def compute_gradients(model, state: TrainState, inputs, y_true, grad_scale: floa
     from . import train_attn  # noqa: F401  (registers the FM / AutoInt / DIN / SASRec forwards)
     fwd = TRAIN_FORWARDS[type(model).__name__]
     tape = Tape(seed)
-    y = None if y_true is None else nn.to_device_f32(y_true, model.device)
+    if isinstance(y_true, (list, tuple)):          # several targets (ESMM: [ctr, cvr])
+        y = [nn.to_device_f32(np.asarray(t, np.float32), model.device) for t in y_true]
+    else:
+        y = None if y_true is None else nn.to_device_f32(y_true, model.device)
     p, loss = fwd(tape, state, model, inputs, y, grad_scale)
     tape.backward()
     return p, loss, tape.grads

@@ -481,5 +481,62 @@ def ncf_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, gra
     return lg, loss
 
 
+def mul_fwd(tape: Tape, a: Var, b: Var) -> Var:
+    y = Var(ops.mul_act(a.v, b.v, None))
+
+    def bwd():
+        g = y.g if y.g.is_contiguous() else y.g.contiguous()
+        a.acc(ops.mul_act(g, b.v, None))
+        b.acc(ops.mul_act(g, a.v, None))
+    tape.ops.append(bwd)
+    return y
+
+
+def bce_prob(tape: Tape, p: Var, y_true: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
+    """mean Keras binary cross-entropy of probabilities p (B, 1) against y; the backward hands dL/dp to p"""
+    yt = y_true.reshape(-1).contiguous()
+    pv = p.v.reshape(-1).contiguous()
+    loss = ops.binary_crossentropy(yt, pv)
+
+    def bwd():
+        n = yt.numel()
+        dp = torch.empty(n, dtype=torch.float32, device=pv.device)
+        C.bce_prob_grad_f32(yt.data_ptr(), pv.data_ptr(), n, grad_scale / n, dp.data_ptr(), _s())
+        p.acc(dp.view(p.v.shape))
+    tape.ops.append(bwd)
+    return loss
+
+
+def esmm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """src/ctr/esmm/model.py:37-92 in training mode with the two-target loss of src/ctr/esmm/train.py:99-103
+    (loss=["binary_crossentropy", "binary_crossentropy"], loss_weights [1, 1] on [pCTR, pCTCVR]).  The user / item DNNs and
+    the embeddings are shared by the two towers: their gradients add up, and their BatchNormalization layers see two
+    batches per step (two moving-average updates, as in Keras).  Returns ([pCTR, pCTCVR], loss_ctr + loss_ctcvr)."""
+    from .train import dnn_fwd, gather_concat_fwd
+    xs = [nn.to_device_f32(t, m.device) for t in inputs]
+    y_ctr, y_cvr = y_true
+    unames = ['embed_' + k + '/embeddings' for k in m.user_cate_feature_dict]
+    inames = ['embed_' + k + '/embeddings' for k in m.item_cate_feature_dict]
+    rate = getattr(m.user_dnn.dropout, "rate", 0.0)
+
+    def tower(head, hname, un, uc, inum, ic):
+        uids = uc[:, m._user_cols].to(torch.int32).contiguous()            # cate_input[:, v[0]] + the Embedding cast (:44-48)
+        iids = ic[:, m._item_cols].to(torch.int32).contiguous()
+        ue = gather_concat_fwd(tape, state, ops.TableGroup(m._user_group.tables), unames, uids)
+        ie = gather_concat_fwd(tape, state, ops.TableGroup(m._item_group.tables), inames, iids)
+        uf = dnn_fwd(tape, m.user_dnn, "user_dnn", concat_fwd(tape, [Var(un), ue]))        # :50-53
+        itf = dnn_fwd(tape, m.item_dnn, "item_dnn", concat_fwd(tape, [Var(inum), ie]))     # :51-54
+        x = dropout_fwd(tape, concat_fwd(tape, [uf, itf]), rate)                            # :56-57
+        x = bn_fwd(tape, head.bn, hname + "/bn", x)                                         # :58
+        x = dense_fwd(tape, head.dense, hname + "/dense", x)                                # :59
+        return dense_fwd(tape, head.out, hname + "/out", x)                                 # :60 (sigmoid)
+    ctr = tower(m.ctr_head, "ctr_head", *xs[:4])
+    cvr = tower(m.cvr_head, "cvr_head", *xs[4:])
+    ctcvr = mul_fwd(tape, ctr, cvr)                                                         # :44
+    l1 = bce_prob(tape, ctr, y_ctr, grad_scale)
+    l2 = bce_prob(tape, ctcvr, y_cvr, grad_scale)
+    return [ctr.v, ctcvr.v], ops.axpby_act(l1.reshape(1), l2.reshape(1), 1.0, 1.0, None)
+
+
 TRAIN_FORWARDS.update({"WideDeep": wide_deep_train_forward, "Deep_Crossing": deep_crossing_train_forward,
-                       "NCF": ncf_train_forward})
+                       "NCF": ncf_train_forward, "ESMM": esmm_train_forward})

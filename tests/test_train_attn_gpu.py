@@ -457,3 +457,43 @@ def test_weight_grad_small_kernel(dev, M, K, N):
     again = torch.empty_like(out)
     C.wgrad_small_f32(tx.data_ptr(), tx.stride(0), tdy.data_ptr(), tdy.stride(0), M, K, N, again.data_ptr(), ws.data_ptr(), stream())
     assert torch.equal(out, again)                                           # deterministic
+
+
+def test_esmm_training_step_two_targets_shared_towers(dev):
+    """ESMM as src/ctr/esmm/train.py trains it: loss = BCE(pCTR, y_ctr) + BCE(pCTR * pCVR, y_cvr), Adam(lr, decay); the
+    user / item DNNs and the embeddings are shared by the two towers (gradients add, their BatchNormalization layers see
+    two batches per step)"""
+    from ctr.esmm.model import ESMM
+    from recamd import train as tr
+    from tests.test_models_gpu import randomize
+    rng = np.random.default_rng(60)
+    user_feats = {f'u{i}': (int(rng.integers(5, 30)), 4) for i in range(3)}
+    item_feats = {f'i{i}': (int(rng.integers(5, 30)), 6) for i in range(2)}
+    user_dict = {k: (i,) for i, k in enumerate(user_feats)}
+    item_dict = {k: (i,) for i, k in enumerate(item_feats)}
+    m = ESMM({**user_feats, **item_feats}, [user_dict, item_dict], hidden_units=[24, 12], embed_reg=1e-4)
+    B = 80
+
+    def tower_inputs():
+        return [rng.random((B, 5)).astype(np.float32),
+                np.stack([rng.integers(0, user_feats[k][0], size=B) for k in user_feats], axis=1).astype(np.float32),
+                rng.random((B, 4)).astype(np.float32),
+                np.stack([rng.integers(0, item_feats[k][0], size=B) for k in item_feats], axis=1).astype(np.float32)]
+    x = tower_inputs() + tower_inputs()
+    y = [(rng.random(B) < 0.4).astype(np.float32), (rng.random(B) < 0.2).astype(np.float32)]
+    m(x)
+    randomize(m, rng, 0.3)
+    for k, v in m.get_weights().items():
+        if k.endswith("gamma"):
+            m.set_weights({k: (1 + 0.1 * rng.normal(size=v.shape)).astype(np.float32)})
+    lr, decay = 3e-3, 1e-2
+    l2 = tr.default_l2(m)
+    W = {k: v.astype(np.float64) for k, v in tr_weights(m).items()}
+    opt, state, oo = tr.Adam(m, lr, l2=l2, decay=decay), tr.TrainState(m), rt.AdamOracle(lr=lr, decay=decay)
+    kw = dict(user_keys=list(user_feats), user_cols=[0, 1, 2], item_keys=list(item_feats), item_cols=[0, 1])
+    for _ in range(3):
+        p, loss = tr.train_step(m, opt, state, x, y)
+        ep, eloss, _ = rt.train_step("esmm", W, oo, x, y, l2, **kw)
+        assert close(p[0].cpu().numpy().reshape(-1), ep[0], floor=1.0) and close(p[1].cpu().numpy().reshape(-1), ep[1], floor=1.0)
+        assert abs(float(loss.item()) - eloss) <= 1e-5 * max(1.0, abs(eloss))
+    check_weights(m, W, lr)
