@@ -539,17 +539,20 @@ constexpr int kWgLdsFloats = 12288;          // 48 KiB of slabs: wide layers tak
 // dY read (conflict-free across the wave) feeds up to JMAX independent FMAs whose X operands are broadcast reads — the
 // first version (outputs p = t, t + 256, ... with the row loop innermost) had one dependent LDS round trip per FMA and ran
 // 0.9 ms per call at SASRec's shape.
-template <int JMAX>
+// VEC (J and K multiples of 4): a thread's J consecutive k values are read four at a time (one broadcast ds_read_b128 per
+// four FMAs; with one read per FMA the K = 64, N = 128 layer of SASRec's FFN ran 0.62 ms per call, LDS-issue bound).
+template <int JMAX, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_small_partial_kernel(const float* __restrict__ x, int64_t ldx,
                                                                   const float* __restrict__ dy, int64_t ldy, int64_t M, int K,
-                                                                  int N, int slab, float* __restrict__ part) {
-  extern __shared__ float wg_lds[];
+                                                                  int N, int J, int slab, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float wg_lds[];
   float* xs = wg_lds;                 // [slab][K]
   float* ds = wg_lds + slab * K;      // [slab][N]
   const int t = threadIdx.x;
-  const int G = 256 / N;              // N <= 256 (host-checked)
+  const int G = 256 / N;              // N <= 256 (host-checked); J = ceil(K / G) <= JMAX
   const int n = t % N, kg = t / N;
-  const bool active = kg < G;
+  const int k0 = kg * J;              // this thread's outputs: (k0 .. k0 + J - 1, n)
+  const bool active = kg < G && k0 < K;
   const int64_t r_begin = (int64_t)blockIdx.x * kWgSpan;
   const int64_t r_end = r_begin + kWgSpan < M ? r_begin + kWgSpan : M;
   float acc[JMAX];
@@ -564,18 +567,31 @@ __global__ __launch_bounds__(256) void wgrad_small_partial_kernel(const float* _
     if (active) {
       for (int r = 0; r < rows; ++r) {
         const float d = ds[r * N + n];
-        const float* xr = xs + r * K + kg;
+        const float* xr = xs + r * K + k0;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < JMAX; ++j)
-          if (kg + j * G < K) acc[j] = fmaf(xr[j * G], d, acc[j]);
+          for (int j = 0; j < JMAX; j += 4) {
+            if (j < J && k0 + j < K) {                 // K, J, k0 multiples of 4: the whole quad is inside
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + j);
+              acc[j] = fmaf(xv.x, d, acc[j]);
+              acc[j + 1] = fmaf(xv.y, d, acc[j + 1]);
+              acc[j + 2] = fmaf(xv.z, d, acc[j + 2]);
+              acc[j + 3] = fmaf(xv.w, d, acc[j + 3]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < JMAX; ++j)
+            if (j < J && k0 + j < K) acc[j] = fmaf(xr[j], d, acc[j]);
+        }
       }
     }
   }
   if (active) {
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
-      const int k = kg + j * G;
-      if (k < K) part[(int64_t)blockIdx.x * K * N + (int64_t)k * N + n] = acc[j];
+      const int k = k0 + j;
+      if (j < J && k < K) part[(int64_t)blockIdx.x * K * N + (int64_t)k * N + n] = acc[j];
     }
   }
 }
@@ -844,15 +860,14 @@ extern "C" int rec_wgrad_small_f32(const float* x, int64_t x_stride, const float
   REC_CHECK_ARG(chunks <= 0x7fffffffLL, REC_ESHAPE, "%s: too many rows", who);
   float* part = reinterpret_cast<float*>(workspace);
   const size_t lds = (size_t)slab * (K + N) * sizeof(float);
-  if (J <= 4)
-    hipLaunchKernelGGL(wgrad_small_partial_kernel<4>, dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, dy_stride, M,
-                       K, N, slab, part);
-  else if (J <= 16)
-    hipLaunchKernelGGL(wgrad_small_partial_kernel<16>, dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, dy_stride,
-                       M, K, N, slab, part);
-  else
-    hipLaunchKernelGGL(wgrad_small_partial_kernel<64>, dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, dy_stride,
-                       M, K, N, slab, part);
+  const bool vec = J % 4 == 0 && K % 4 == 0;
+#define REC_WG(JM_, V_)                                                                                                   \
+  hipLaunchKernelGGL((wgrad_small_partial_kernel<JM_, V_>), dim3((unsigned)chunks), dim3(256), lds, st, x, x_stride, dy, \
+                     dy_stride, M, K, N, J, slab, part)
+  if (J <= 4) { if (vec) REC_WG(4, true); else REC_WG(4, false); }
+  else if (J <= 16) { if (vec) REC_WG(16, true); else REC_WG(16, false); }
+  else { if (vec) REC_WG(64, true); else REC_WG(64, false); }
+#undef REC_WG
   REC_CHECK_LAUNCH(who);
   const int64_t P = (int64_t)K * N;
   // out[p] = sum over the chunks, fixed order, fp64 across 256-chunk groups (rec_colsum_f32 over the (chunks, P) partials)
