@@ -453,6 +453,13 @@ int rec_gather_dot_scores_grad_f32(const float* seq, const float* table, float* 
 int rec_fm_onehot_grad_f32(const float* dense, int64_t dense_stride, int32_t n_dense, const int32_t* ids,
                            int64_t ids_stride, int32_t F, const int32_t* vocab, const float* V, int32_t k,
                            const float* dlogit, int64_t B, float* dw, float* dV, void* stream);
+/* out (M, N contiguous) = x W for x (M, K) with row stride x_stride and W (K, N), no bias / activation, when M x N is a
+ * handful of 128 x 128 tiles and K is long (the weight gradient dW = X^T dY of a Dense layer: M = its input width, K =
+ * the batch): the reduction is split over gridDim.y slices on the bf16x3 kernel (fp32-accurate) and the slices are summed
+ * in a fixed order in fp64.  workspace: rec_dense_splitk_workspace_bytes(M, K, N). */
+int64_t rec_dense_splitk_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int rec_dense_splitk_f32(const float* x, int64_t x_stride, const float* W, int64_t M, int32_t K, int32_t N, float* out,
+                         void* workspace, void* stream);
 /* Weight gradient of a Dense layer with a SMALL kernel and a LONG batch axis: out (K, N) = x^T dy for x (M, K), dy
  * (M, N), N <= 256 and K <= 64 * (256 / N) — the rows are split over workgroups and the partials summed in a fixed order (deterministic),
  * where rec_dense_f32 on the transposed operand would walk all M rows in one or two workgroups (the projections of

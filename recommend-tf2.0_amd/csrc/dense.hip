@@ -352,7 +352,11 @@ static int dense_impl_f32(const char* who, const float* x, int64_t x_stride, con
     return REC_OK;
   }
   // large layers: bf16x3 on the bf16 matrix cores (fp32-accurate, 2.7x the fp32 MFMA peak)
-  const bool big = N > 8 && (dense_impl() == 'b' || (M >= 1024 && (int64_t)K * N >= 64 * 64));
+  // ... and few-row products with a LONG reduction (the weight gradients dW = X^T dY of the training step: M = the
+  // layer's input width, K = the batch): on the fp32-MFMA tile kernel 479 x 8192 x 1024 took 1.2 ms and six of them
+  // were 62 % of a DLRM training step
+  const bool big = N > 8 && (dense_impl() == 'b' || (M >= 1024 && (int64_t)K * N >= 64 * 64) ||
+                             (M >= 128 && K >= 2048 && (int64_t)K * N >= 64 * 64));
   if (big && dense_impl() != 't' && dense_impl() != 'f' &&
       dense_bf16x3_dispatch(x, x_stride, W, prepared, bias, alpha, act, M, K, N, out, out_stride, st)) {
     REC_CHECK_LAUNCH(who);
@@ -380,6 +384,49 @@ extern "C" int rec_dense_f32(const float* x, int64_t x_stride, const float* W, c
                              const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
                              float* out, int64_t out_stride, void* stream) {
   return dense_impl_f32("rec_dense_f32", x, x_stride, W, nullptr, bias, alpha, act, M, K, N, out, out_stride, stream);
+}
+
+// ---- few output tiles, long reduction: split-K on the bf16x3 kernel ------------------------------------------------------
+namespace rec {
+bool dense_bf16x3_splitk(const float* x, int64_t x_stride, const float* W, int64_t M, int K, int N, int splits, int Kc,
+                         float* out_parts, hipStream_t st);
+}
+
+static int splitk_plan(int64_t M, int32_t K, int32_t N, int* Kc) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int splits = (int)((512 + tiles - 1) / tiles);                    // ~2 workgroups per CU in flight
+  const int max_by_k = K / 512 > 1 ? K / 512 : 1;                  // at least 512 reduction steps per slice
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits > 64) splits = 64;
+  int kc = (K + splits - 1) / splits;
+  kc = (kc + 15) / 16 * 16;
+  splits = (K + kc - 1) / kc;
+  *Kc = kc;
+  return splits;
+}
+
+extern "C" int64_t rec_dense_splitk_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+  if (M < 1 || K < 1 || N < 1) return 0;
+  int kc;
+  const int splits = splitk_plan(M, K, N, &kc);
+  return (int64_t)splits * M * N * (int64_t)sizeof(float) + rec_colsum_workspace_bytes(splits, M * N);
+}
+
+extern "C" int rec_dense_splitk_f32(const float* x, int64_t x_stride, const float* W, int64_t M, int32_t K, int32_t N,
+                                    float* out, void* workspace, void* stream) {
+  const char* who = "rec_dense_splitk_f32";
+  REC_CHECK_ARG(x && W && out && workspace, REC_EINVAL, "%s: NULL pointer", who);
+  REC_CHECK_ARG(M >= 1 && K >= 1 && N >= 1 && x_stride >= K, REC_ESHAPE, "%s: bad shape", who);
+  REC_CHECK_ARG(M * (int64_t)N <= 0x7fffffffLL, REC_ESHAPE, "%s: output too large", who);
+  int kc;
+  const int splits = splitk_plan(M, K, N, &kc);
+  float* parts = static_cast<float*>(workspace);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  REC_CHECK_ARG(dense_bf16x3_splitk(x, x_stride, W, M, K, N, splits, kc, parts, st), REC_ESHAPE, "%s: grid too large", who);
+  REC_CHECK_LAUNCH(who);
+  // out = sum of the slices, fixed order, fp64 (deterministic)
+  return rec_colsum_f32(parts, M * (int64_t)N, nullptr, 0, nullptr, splits, M * (int64_t)N, out, parts + (int64_t)splits * M * N,
+                        stream);
 }
 
 extern "C" int64_t rec_dense_prepared_bytes(int32_t K, int32_t N) {

@@ -49,9 +49,18 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
                                                               const float* __restrict__ alpha, int act, int64_t M,
                                                               int K, int N, float* __restrict__ out,
                                                               int64_t out_stride, int out_vec, const u32x4* __restrict__ Wp, int Np,
-                                                              int xcd_map) {
+                                                              int xcd_map, int Kc = 0, int64_t out_split = 0) {
   using namespace b3;
   constexpr int x_vec = XMODE;
+  // split-K (rec_dense_splitk_f32; gridDim.y slices of Kc reduction steps each, Kc a multiple of 16): slice y multiplies
+  // columns [y Kc, (y + 1) Kc) of x by the matching rows of W into its own partial output
+  if (Kc > 0) {
+    const int ks = blockIdx.y;
+    x += (int64_t)ks * Kc;
+    W += (int64_t)ks * Kc * N;
+    K = K - ks * Kc < Kc ? K - ks * Kc : Kc;
+    out += (int64_t)ks * out_split;
+  }
   // [stage][operand A/B][plane h/m/l][kh][row] of 16-B fragments: 2*2*3*2*128*16 B = 48 KiB
   __shared__ u32x4 frag[2][2][3][2][128];
   // rows of x that are not 16-B aligned (x_stride % 4 != 0, e.g. a tight (M, 479) matrix) cannot be read as two
@@ -463,6 +472,29 @@ __global__ __launch_bounds__(256) void dense_prepare_kernel(const float* __restr
   Wp[((int64_t)k8 * 3 + 0) * Np + n] = h;
   Wp[((int64_t)k8 * 3 + 1) * Np + n] = m;
   Wp[((int64_t)k8 * 3 + 2) * Np + n] = l;
+}
+
+// out_parts[s] (M, N contiguous) = x[:, s Kc : (s + 1) Kc] W[s Kc : (s + 1) Kc, :] for s < splits, in ONE launch (no bias, no
+// activation): the reduction axis of a few-tile product is spread over gridDim.y
+bool dense_bf16x3_splitk(const float* x, int64_t x_stride, const float* W, int64_t M, int K, int N, int splits, int Kc,
+                         float* out_parts, hipStream_t st) {
+  const int64_t gx = (M + b3::BM - 1) / b3::BM;
+  const int gy = (N + b3::BN - 1) / b3::BN;
+  const int x_vec = (aligned16(x) && x_stride % 4 == 0) ? 1 : (Kc >= 64 ? 2 : 0);
+  const int64_t total = ((gx + 7) / 8) * 8 * gy;
+  if (total > 0x7fffffffLL || splits > 65535) return false;
+  const dim3 grid((unsigned)total, (unsigned)splits);
+  const int out_vec = (aligned16(out_parts) && N % 4 == 0) ? 1 : 0;
+  const int Np = (N + 127) / 128 * 128;
+#define REC_B3_SK(XM_)                                                                                                  \
+  hipLaunchKernelGGL((dense_bf16x3_kernel<XM_, false>), grid, dim3(256), 0, st, x, x_stride, W, (const float*)nullptr,    \
+                     (const float*)nullptr, (int)REC_ACT_NONE, M, K, N, out_parts, (int64_t)N, out_vec,                   \
+                     (const u32x4*)nullptr, Np, 0, Kc, M * (int64_t)N)
+  if (x_vec == 1) REC_B3_SK(1);
+  else if (x_vec == 2) REC_B3_SK(2);
+  else REC_B3_SK(0);
+#undef REC_B3_SK
+  return true;
 }
 
 // caller has validated shapes/pointers (rec_dense_f32 / rec_dense_prep_f32); Wp may be NULL

@@ -711,6 +711,12 @@ PYBIND11_MODULE(_C, m) {
     check(rec_bce_prob_grad_f32(P<const float>(y), P<const float>(p), n, scale, P<float>(dp), P<void>(stream)),
           "rec_bce_prob_grad_f32");
   });
+  m.def("dense_splitk_workspace_bytes", [](int64_t M, int K, int N) { return rec_dense_splitk_workspace_bytes(M, K, N); });
+  m.def("dense_splitk_f32", [](ptr_t x, int64_t xs, ptr_t W, int64_t M, int K, int N, ptr_t out, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dense_splitk_f32(P<const float>(x), xs, P<const float>(W), M, K, N, P<float>(out), P<void>(ws), P<void>(stream)),
+          "rec_dense_splitk_f32");
+  });
   m.def("dropout_f32", [](ptr_t x, int64_t n, float rate, uint64_t seed, ptr_t y, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_dropout_f32(P<const float>(x), n, rate, seed, P<float>(y), P<void>(stream)), "rec_dropout_f32");

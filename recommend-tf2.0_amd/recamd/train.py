@@ -62,7 +62,15 @@ def weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
         C.wgrad_small_f32(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), M, K, N, out.data_ptr(), ws.data_ptr(), _s())
         return out
     xc = x if x.is_contiguous() else x.contiguous()
-    return ops.dense(transpose(xc), dy)
+    xt = transpose(xc)                                  # (K, M): the batch is the reduction axis of dW
+    if M >= 2048 and ((K + 127) // 128) * ((N + 127) // 128) < 128 and dy.is_contiguous() and N > 8:
+        # a handful of output tiles under a long reduction: split-K (rec_dense_splitk_f32) instead of a few workgroups
+        # walking the whole batch
+        out = torch.empty((K, N), dtype=torch.float32, device=x.device)
+        ws = _ws(C.dense_splitk_workspace_bytes(K, M, N), x.device)
+        C.dense_splitk_f32(xt.data_ptr(), xt.stride(0), dy.data_ptr(), K, M, N, out.data_ptr(), ws.data_ptr(), _s())
+        return out
+    return ops.dense(xt, dy)
 
 
 def sum_squares(t: torch.Tensor) -> torch.Tensor:

@@ -90,3 +90,25 @@ def test_dense_bf16x3_tiny_and_mixed_magnitudes(dev, monkeypatch):
     exp = x.astype(np.float64) @ W.astype(np.float64)
     scale = np.abs(x.astype(np.float64)) @ np.abs(W.astype(np.float64))
     assert np.all(np.abs(got - exp) <= 2e-6 * scale + 1e-30)   # a-priori fp32 bound is K * 2^-24 = 7.6e-6
+
+
+@pytest.mark.parametrize("M,K,N", [(479, 8192, 1024), (13, 8192, 512), (128, 2048, 9), (64, 5000, 64), (300, 2049, 130), (1, 600, 1)])
+def test_dense_splitk(dev, M, K, N):
+    """rec_dense_splitk_f32: x W with the reduction axis spread over gridDim.y on the bf16x3 kernel, partials summed in a
+    fixed order — the weight-gradient shape (few output tiles, K = the batch).  fp32-accurate like the forward kernel."""
+    import torch
+    from recamd._lib import C
+    rng = np.random.default_rng(M + N)
+    x, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+    tx, tw = torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev)
+    out = torch.empty((M, N), device=dev)
+    ws = torch.empty(int(C.dense_splitk_workspace_bytes(M, K, N)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    C.dense_splitk_f32(tx.data_ptr(), tx.stride(0), tw.data_ptr(), M, K, N, out.data_ptr(), ws.data_ptr(), st)
+    exp = x.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64)
+    from tests.util import close_scaled
+    assert close_scaled(out.cpu().numpy(), exp, scale)
+    again = torch.empty_like(out)
+    C.dense_splitk_f32(tx.data_ptr(), tx.stride(0), tw.data_ptr(), M, K, N, again.data_ptr(), ws.data_ptr(), st)
+    assert torch.equal(out, again)                              # deterministic

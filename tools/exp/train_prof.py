@@ -1,4 +1,4 @@
-"""per-kernel split of one training step (run under rocprofv3 --kernel-trace --stats): python tools/exp/train_prof.py autoint|sasrec"""
+"""per-kernel split of one training step (run under rocprofv3 --kernel-trace --stats): python tools/exp/train_prof.py autoint|sasrec|dlrm"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,12 @@ if which == "autoint":
     F, nd, B = 26, 13, 4096
     m = AutoInt([[{'feat': f'I{i}'} for i in range(nd)], [{'feat': f'C{i}', 'feat_num': V, 'embed_dim': 16} for i in range(F)]],
                 att_hidden_units=16, head_num=2, att_layer_num=3, use_res=True)
+    inputs, y = [rng.random((B, nd)).astype(np.float32), rng.integers(0, V, size=(B, F)).astype(np.int32)], (rng.random(B) < 0.3).astype(np.float32)
+elif which == "dlrm":
+    from ctr.dlrm.model import DLRM
+    F, nd, B = 26, 13, 8192
+    m = DLRM([[{'feat': f'I{i}'} for i in range(nd)], [{'feat': f'C{i}', 'feat_num': V, 'embed_dim': 128} for i in range(F)]],
+             [512, 256, 128], [1024, 512, 256], interaction='dot')
     inputs, y = [rng.random((B, nd)).astype(np.float32), rng.integers(0, V, size=(B, F)).astype(np.int32)], (rng.random(B) < 0.3).astype(np.float32)
 else:
     from match.sasrec.model import SASRec
