@@ -310,8 +310,14 @@ __device__ __forceinline__ void stage_weights(f32x4* __restrict__ wl, const floa
 }
 }  // namespace cf32
 
+// workgroups per CU the register budget is cut for (tools/exp/autoint_wg_ab.sh, configs[2], same box): unconstrained 196 VGPRs
+// (two waves per SIMD) 83.6 us; 2 -> 176 VGPRs 80.8 us; 3 -> 168 VGPRs + 2 spilled, three waves per SIMD, 76.6 us (shipped):
+// a third wave per SIMD overlaps one sample's softmax VALU with another's matrix work
+#ifndef REC_AUTOINT_MINWG
+#define REC_AUTOINT_MINWG 3
+#endif
 template <int NT, int KS0, int H, int ACT, bool IO = false>
-__global__ __launch_bounds__(256) void mha_ctr_stack_kernel(const float* __restrict__ x, int64_t B, int N, CtrStackArgs wa,
+__global__ __launch_bounds__(256, REC_AUTOINT_MINWG) void mha_ctr_stack_kernel(const float* __restrict__ x, int64_t B, int N, CtrStackArgs wa,
                                                             int L, int act, float* __restrict__ out, CtrFusedIo io = {}) {
   using namespace cf32;
   extern __shared__ __attribute__((aligned(16))) f32x4 wstack[];
@@ -408,7 +414,10 @@ bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const Ctr
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   int64_t blocks = (B + 3) / 4;
-  if (blocks > (int64_t)cus * 4) blocks = (int64_t)cus * 4;   // 16 waves per CU, each looping over its samples
+  // workgroups per CU that are RESIDENT at once (the kernels use 196 VGPRs: two waves per SIMD = two workgroups of four
+  // waves): with more, the surplus workgroups run as a second round and stage the weights again.  REC_AUTOINT_WG_PER_CU: A/B
+  static const int wg_per_cu = [] { const char* e = getenv("REC_AUTOINT_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : REC_AUTOINT_MINWG; }();
+  if (blocks > (int64_t)cus * wg_per_cu) blocks = (int64_t)cus * wg_per_cu;
   const dim3 grid((unsigned)blocks), block(256);
 #define REC_CST(NT_, KS_, H_)                                                                                       \
   do {                                                                                                              \
