@@ -283,7 +283,13 @@ __device__ __forceinline__ void gl16(u32x4& dst, const void* p) {
 #define REC_DWAIT_W(n, tok, a, b, c) \
   asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b), "v"(c) : "memory")
 
-__global__ __launch_bounds__(256, 2) void dense_bf16x3_pipe_kernel(const float* __restrict__ x, int64_t x_stride,
+// register budget for three workgroups per CU (168 VGPRs + 1 spilled; unconstrained: 172, one over the three-per-CU limit):
+// 65 536 x 1024 x 512 184 -> 189 TFLOP/s, 8192 x 4096 x 4096 205 -> 206.5 (tools/exp/dense_wg_ab.sh): the kernel is bound by
+// its LDS operand traffic, not by occupancy
+#ifndef REC_DENSE_PIPE_WG
+#define REC_DENSE_PIPE_WG 3
+#endif
+__global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kernel(const float* __restrict__ x, int64_t x_stride,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ alpha, int act, int64_t M,
                                                                    int K, int N, float* __restrict__ out,
