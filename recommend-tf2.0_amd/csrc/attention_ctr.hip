@@ -317,7 +317,8 @@ __device__ __forceinline__ void stage_weights(f32x4* __restrict__ wl, const floa
 #define REC_AUTOINT_MINWG 3
 #endif
 template <int NT, int KS0, int H, int ACT, bool IO = false>
-__global__ __launch_bounds__(256, REC_AUTOINT_MINWG) void mha_ctr_stack_kernel(const float* __restrict__ x, int64_t B, int N, CtrStackArgs wa,
+// (wider shapes — NT = 4 or din = 32 with two heads — would spill 26-62 registers under that budget: they keep two)
+__global__ __launch_bounds__(256, (NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2) void mha_ctr_stack_kernel(const float* __restrict__ x, int64_t B, int N, CtrStackArgs wa,
                                                             int L, int act, float* __restrict__ out, CtrFusedIo io = {}) {
   using namespace cf32;
   extern __shared__ __attribute__((aligned(16))) f32x4 wstack[];
@@ -416,8 +417,9 @@ bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const Ctr
   int64_t blocks = (B + 3) / 4;
   // workgroups per CU that are RESIDENT at once (the kernels use 196 VGPRs: two waves per SIMD = two workgroups of four
   // waves): with more, the surplus workgroups run as a second round and stage the weights again.  REC_AUTOINT_WG_PER_CU: A/B
-  static const int wg_per_cu = [] { const char* e = getenv("REC_AUTOINT_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : REC_AUTOINT_MINWG; }();
-  if (blocks > (int64_t)cus * wg_per_cu) blocks = (int64_t)cus * wg_per_cu;
+  static const int wg_per_cu = [] { const char* e = getenv("REC_AUTOINT_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v; }();
+  const int wg_res = wg_per_cu > 0 ? wg_per_cu : ((NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2);   // as the kernel's launch bounds
+  if (blocks > (int64_t)cus * wg_res) blocks = (int64_t)cus * wg_res;
   const dim3 grid((unsigned)blocks), block(256);
 #define REC_CST(NT_, KS_, H_)                                                                                       \
   do {                                                                                                              \
