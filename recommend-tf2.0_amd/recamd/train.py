@@ -617,6 +617,10 @@ class Trainer:
 
     def compile(self, optimizer: Optional[Adam] = None, learning_rate: float = 1e-3, sparse_embeddings: bool = False,
                 allreduce: Optional[Callable] = None, world: int = 1):
+        if isinstance(optimizer, str):
+            if optimizer.lower() != "adam":
+                raise NotImplementedError(f"optimizer {optimizer!r}: the reference's train scripts all use Adam")
+            optimizer = None
         self.opt = optimizer or Adam(self.model, learning_rate, l2=default_l2(self.model), sparse_embeddings=sparse_embeddings)
         self.allreduce, self.world = allreduce, world
         return self
