@@ -385,3 +385,15 @@ def test_fit_evaluate_early_stopping_checkpoint(dev, tmp_path):
     trainer.load_weights(path)
     after = trainer.evaluate(inputs, y)
     assert before == after
+
+
+def test_compile_accepts_the_keras_optimizer_string(dev):
+    """INTEGRATION.md §A writes tr.compile(optimizer='adam', learning_rate=...) as the reference's scripts do"""
+    from recamd import train as tr
+    m, _, _, inputs, y = _setup("dcn", dev, np.random.default_rng(5), B=32)
+    t = tr.Trainer(m).compile(optimizer='adam', learning_rate=1e-3)
+    assert isinstance(t.opt, tr.Adam) and t.opt.lr0 == 1e-3
+    with pytest.raises(NotImplementedError):
+        tr.Trainer(m).compile(optimizer='sgd')
+    hist = t.fit(inputs, y, batch_size=16, epochs=1)
+    assert len(hist["loss"]) == 1 and np.isfinite(hist["loss"][0])
