@@ -87,7 +87,8 @@ def place_table_arena(F: int, V: int, D: int, device, candidates: int = 4, probe
     fused_lottery.py; profiles/r02c_*lottery*.txt).  Result, dense and id buffers do not matter (<= 1 %).  Tables are
     allocated once and read for the life of the model, and 288 GB of HBM leave room to choose: `candidates` arenas are
     allocated side by side (all alive, so they are distinct memory), `probe(group, i)` — one launch of the kernel the
-    tables will serve, i = launch counter — is timed on each, the fastest is kept and the rest are freed.  Default probe:
+    tables will serve, i = launch counter; or a list of such probes, whose normalised times are added — is timed on
+    each, the fastest is kept and the rest are freed.  Default probe:
     the materialised gather over uniform ids.  Returns (arena, info) with the probe time of every candidate — callers
     report them (bench.py does).  candidates <= 1: one plain allocation, no probe."""
     dev = torch.device(device)
@@ -110,28 +111,32 @@ def place_table_arena(F: int, V: int, D: int, device, candidates: int = 4, probe
         arenas.append(a)
     a = None
     groups = [TableGroup([t[f] for f in range(F)]) for t in arenas]
-    for i in range(max(100, 8 * probe_launches)):   # clocks up before anything is compared (the first ~100 ms after idle
-        probe(groups[0], i)                         # run up to 25 % slower)
-    times = [float("inf")] * len(arenas)
+    probes = list(probe) if isinstance(probe, (list, tuple)) else [probe]     # several kernels: the sum of their
+    for i in range(max(100, 8 * probe_launches)):   # clocks up before anything is compared   # normalised times decides
+        probes[0](groups[0], i)                     # (the first ~100 ms after idle run up to 25 % slower)
+    times = [[float("inf")] * len(arenas) for _ in probes]
     for _rep in range(2):                           # two interleaved passes, the faster one counts
         for k, g in enumerate(groups):
-            for i in range(2):
-                probe(g, i)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(probe_launches):
-                probe(g, i)
-            e1.record()
-            e1.synchronize()
-            times[k] = min(times[k], e0.elapsed_time(e1) / probe_launches * 1e3)
+            for pi, pr in enumerate(probes):
+                for i in range(2):
+                    pr(g, i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(probe_launches):
+                    pr(g, i)
+                e1.record()
+                e1.synchronize()
+                times[pi][k] = min(times[pi][k], e0.elapsed_time(e1) / probe_launches * 1e3)
     g = None
     del groups
-    best = min(range(len(arenas)), key=lambda i: times[i])
+    score = [sum(t[k] / min(t) for t in times) for k in range(len(arenas))]
+    best = min(range(len(arenas)), key=lambda k: score[k])
     arena = arenas[best]
     del arenas
     torch.cuda.empty_cache()
-    return arena, {"candidates": len(times), "probe": probe_name or "caller's kernel", "probe_us": [round(t, 1) for t in times],
-                   "chosen": best}
+    rounded = [[round(v, 1) for v in t] for t in times]
+    return arena, {"candidates": len(score), "probe": probe_name or "caller's kernel",
+                   "probe_us": rounded[0] if len(rounded) == 1 else rounded, "chosen": best}
 
 
 def new_oob_flag(device) -> torch.Tensor:
