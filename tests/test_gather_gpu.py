@@ -162,3 +162,5 @@ def test_place_table_arena_reports_every_candidate(dev):
     assert tuple(plain.shape) == (F, V, D) and info1 == {"candidates": 1}
     dflt, info2 = ops.place_table_arena(2, 1000, 16, dev, candidates=2, probe_launches=2)   # default probe: the gather
     assert tuple(dflt.shape) == (2, 1000, 16) and len(info2["probe_us"]) == 2
+    both, info3 = ops.place_table_arena(F, V, D, dev, candidates=2, probe=[probe, probe], probe_launches=2)   # several kernels
+    assert tuple(both.shape) == (F, V, D) and len(info3["probe_us"]) == 2 and all(len(t) == 2 for t in info3["probe_us"])
