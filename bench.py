@@ -18,19 +18,29 @@ Untimed: a device spin-up (>= 0.3 s of steps: clocks and TLBs settle; the first 
 `value` = units of all ranks / max-over-ranks wall time.  A second, separate pass brackets every launch with
 its own HIP events for the p10/p50/p90 in `launch_us`.
 
-Table placement: the time of both DLRM kernels depends on which physical memory the 13.3 GB of tables received (same
-box, same kernel: gather 307-329 us, fused 165-182 us by allocation; DESIGN.md section 5 'Placement').  By default the
-tables are placed by measurement (recamd.ops.place_table_arena): --arena-candidates N (default 6) arenas are allocated
-side by side, this workload's own step is timed on each, the fastest is kept; EVERY candidate's probe time is printed
-in config.table_placement.  --arena-candidates 1 = one plain allocation.
+The default N = 1 line also carries, measured in the same run: `gather_roofline` (the north-star kernel), `zipf` (the
+headline step on Zipf(1.05) ids), `configs` (BASELINE configs[2..4]: autoint / din / sasrec with their own rooflines),
+`placed` (see below), `pcie_inclusive`, `cpu_baseline`.
 
-Multi-GPU (driver: torch.distributed.run, one rank per GPU, RCCL): weak scaling, the same batch per GPU.
+Table placement: the time of both DLRM kernels depends on which physical memory the 13.3 GB of tables received (same
+box, same kernel: gather 300-329 us, fused 165-182 us by allocation).  Round 3 looked for the cause (profiles/
+r03_placement_probe.txt: not the allocation call — hipMalloc, contiguous, VMM chunks of 2 MiB..1 GiB all show the same
+per-arena spread; the per-arena UTCL1 / multi-miss counters differ, i.e. the page-table fragments the driver builds for
+whatever physical blocks it had) and found no user-space control.  The HEADLINE therefore runs on ONE PLAIN ALLOCATION
+(--arena-candidates 1, the default); the measured placement (recamd.ops.place_table_arena: N arenas side by side, this
+workload's step timed on each, the fastest kept) is reported beside it as `placed` (N = --placed-candidates, 0 = skip).
+
+Multi-GPU: `python bench.py --gpus N` starts its own N rank processes (one per GPU, before anything touches a GPU) when
+no launcher did (no WORLD_SIZE in the environment); under `python -m torch.distributed.run` it is one of the ranks.
+Weak scaling, the same batch per GPU.
   --placement replicated (default): every GPU holds all tables (13.3 GB of 288 GB), as the reference's
       MirroredStrategy mirrors its variables (src/ctr/fm/train.py:43); the forward has no collective.
   --placement rowshard: tables row-sharded cyclically (owner = id % G) behind the RCCL all-to-all pair
-      (recamd.dist.ShardedTables) — xGMI-bound for uniform ids.
+      (recamd.dist.ShardedTables): rows this rank owns are read in place, ids + rows of batch i+1 travel on a
+      communication stream while batch i's fused kernel runs — xGMI-bound for uniform ids.
   With N > 1 the replicated line also carries a "rowshard" object measured in the same run (and vice versa
-  the placement is named in config.placement), so a scaling run reports both.
+  the placement is named in config.placement), so a scaling run reports both; `exchange` says which transport ran
+  and how many ranks the RCCL communicator itself reported.
 
 Prints ONE JSON line on rank 0.
 """
@@ -53,11 +63,11 @@ NB = 8                         # distinct id batches rotated over the steps
 
 
 def pmc_traffic(kernel_substr, cfg):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2
-    (gfx950 correction) + WRITE_SIZE, separate --pmc runs of this same bench).  PMC counters cannot be read from
-    inside the timed run, so `traffic` is the latest committed measurement for the SAME workload shape, or None."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic[_<workload>].json:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs of this same bench).  PMC counters cannot be
+    read from inside the timed run, so `traffic` is the latest committed measurement for the SAME workload shape, or None."""
     import glob
-    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))):
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))):
         try:
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
@@ -83,8 +93,12 @@ def parse():
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=0, help="rows per table (0 = the BASELINE config's vocabulary)")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--arena-candidates", type=int, default=6,
-                    help="table arenas allocated and probed before one is kept (1 = a plain allocation)")
+    ap.add_argument("--arena-candidates", type=int, default=1,
+                    help="table arenas allocated and probed before one is kept for the HEADLINE (1 = a plain allocation)")
+    ap.add_argument("--placed-candidates", type=int, default=6,
+                    help="side measurement `placed`: the headline step on the best of this many arenas (0 = skip)")
+    ap.add_argument("--cache-rows", type=int, default=0, help="rowshard: hot-row replicas per rank (0 = off)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-spawned N > 1 run: watchdog of the rank processes (s)")
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=16384)
@@ -142,25 +156,29 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
         group = ops.TableGroup([arena[f] for f in range(F)])
     else:
         from recamd.dist import ShardedTables
-        rows_local = (V + world - 1 - rank) // world  # rows r with r % world == rank
-        arena = torch.empty((F, rows_local, D), dtype=torch.float32, device=dev)
+        # shard + replica cache + receive slots in ONE allocation (the row space the consumer kernels address)
+        sharded = ShardedTables.empty(F, [V] * F, D, rank, world, dev, max_ids=B * F, cache_rows=a.cache_rows,
+                                      cache_refresh_every=16 if a.cache_rows else 0)
+        arena = sharded.arena
         arena.uniform_(-0.05, 0.05, generator=gen)
-        sharded = ShardedTables([arena[f] for f in range(F)], [V] * F, rank, world)
         group = None
 
-    def step_fused(i):
-        if sharded is None:
-            ops.gather_pairwise_dot(group, ids[i % NB], dense, out=out_fused)
-        else:  # the plan (dedup, bucketing, count exchange) of the NEXT batch is issued behind this batch's lookup
-            sharded.lookup_pairwise_dot(ids[i % NB], dense, out=out_fused)
-            sharded.prefetch(ids[(i + 1) % NB])
+    def pipelined(consume):
+        # plan two batches ahead, ids + rows one batch ahead (communication stream), consume this one (compute stream):
+        # the exchange of batch i+1 overlaps batch i's kernel, and the plan's count matrix is on the host before the
+        # exchange that needs it is issued
+        def step(i):
+            sharded.prefetch(ids[(i + 2) % NB])
+            sharded.prefetch(ids[(i + 1) % NB], rows=True)
+            consume(ids[i % NB])
+        return step
 
-    def step_gather(i):
-        if sharded is None:
-            ops.gather_concat(group, ids[i % NB], out=out_gather)
-        else:
-            sharded.lookup(ids[i % NB], out=out_gather)
-            sharded.prefetch(ids[(i + 1) % NB])
+    if sharded is None:
+        step_fused = lambda i: ops.gather_pairwise_dot(group, ids[i % NB], dense, out=out_fused)  # noqa: E731
+        step_gather = lambda i: ops.gather_concat(group, ids[i % NB], out=out_gather)  # noqa: E731
+    else:
+        step_fused = pipelined(lambda t: sharded.lookup_pairwise_dot(t, dense, out=out_fused))
+        step_gather = pipelined(lambda t: sharded.lookup(t, out=out_gather))
 
     bytes_fused = B * (F * D * 4 + F * 4 + D * 4 + (P + D) * 4)     # 15 844 B/sample at 26x128
     bytes_gather = B * F * (2 * D * 4 + 4)                            # 26 728 B/sample at 26x128
@@ -169,7 +187,7 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
         "units": B, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shape_cfg": shape_cfg,
         "config": {"batch_per_gpu": B, "global_batch": B * world, "fields": F, "vocab_per_table": V, "dim": D,
                    "ids": a.ids, "id_batches_rotated": NB},
-        "arena": arena, "ids": ids, "dense": dense, "sharded": sharded,
+        "arena": arena, "ids": ids, "dense": dense, "sharded": sharded, "out_fused": out_fused, "group": group,
     }
     if placed is not None:
         w["config"]["table_placement"] = placed
@@ -236,12 +254,13 @@ def wl_din(torch, dev, a, rank, world):
     # exactly 0 and are not fetched), q in, pooled row out
     need = B * (T * 3 * 4 + 2 * d * 4) + (real_slots / NB) * d * 4
     return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "kernel": "rec::din_gather_pool_grp_kernel<0, 3> (fused history lookup + attention pooling, one 16-lane group per slot)", "pmc_key": None,
+            "kernel": "rec::din_gather_pool_grp_kernel<0, 3> (fused history lookup + attention pooling, one 16-lane group per slot)",
+            "pmc_key": "din_gather_pool_grp_kernel",
             "workload": "DIN var-len user history (max 100) attention pooling, batch 8192 (BASELINE configs[3])",
             "config": {"batch_per_gpu": B, "global_batch": B * world, "maxlen": T, "d": d, "vocab_per_table": V,
                        "mean_real_slots": round(real_slots / NB / B, 2),
                        "bytes_note": "rows of real (non-pad) history slots only + all ids + q + out"},
-            "side_gather": None, "shape_cfg": {}}
+            "side_gather": None, "shape_cfg": {"workload": "din", "batch": B, "vocab": V, "ids": a.ids}}
 
 
 def wl_sasrec(torch, dev, a, rank, world):
@@ -273,14 +292,15 @@ def wl_sasrec(torch, dev, a, rank, world):
     need = B * ((S + 1 + n) * 4 + (1 + n) * d * 4 + (1 + n) * 4) + (real / NB) * d * 4
     return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": "sasrec_last_row_kernel (rec_sasrec_last_row_f32): the whole forward in one launch, exact last-row "
-                      "form, item rows of real positions read once", "pmc_key": None,
+                      "form, item rows of real positions read once", "pmc_key": "sasrec_last_row_kernel",
             "workload": "SASRec seq 200 dim 64, 10M-item tables, 1 block, 100 negatives, global batch 8192 "
                         "(BASELINE configs[4])" + (", tables row-sharded over the ranks (RCCL all-to-all)"
                                                    if a.placement == "rowshard" else ""),
             "config": {"batch_per_gpu": B, "global_batch": B * world, "seq_len": S, "neg_len": n, "d": d,
                        "vocab_per_table": V, "mean_real_positions": round(real / NB / B, 2),
                        "bytes_note": "item rows of real positions + pos/neg rows + ids + logits"},
-            "side_gather": None, "shape_cfg": {}, "sharded": getattr(m, "_sharded", None)}
+            "side_gather": None, "shape_cfg": {"workload": "sasrec", "batch": B, "vocab": V, "ids": a.ids},
+            "sharded": getattr(m, "_sharded", None)}
 
 
 SIDE_WORKLOADS = ("dlrm_fused", "gather", "sasrec")
@@ -328,8 +348,95 @@ def collect_side_leg(alt, proc, timeout):
             "launch_us": r["roofline"]["launch_us"], "exchange": r["config"].get("exchange")}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: THIS process never touches a GPU (no torch import, no HIP call);
+    it starts the N rank processes — the same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, one GPU each — relays rank 0's JSON line and exits with the worst return code.  A rank that dies takes
+    the others down (their exact PIDs); --launch-timeout bounds the whole run."""
+    import socket
+    import subprocess
+    import threading
+    n = a.gpus
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REC_BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    deadline = time.time() + a.launch_timeout
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = max(abs(c) for c in codes)
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            why = f"rank {bad[0][0]} exited with {bad[0][1]}" if bad else f"no result after {a.launch_timeout:.0f} s"
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            rc = 1
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    out = [ln for ln in lines if ln.startswith("{")]
+    if out:
+        print(out[-1].rstrip(), flush=True)
+    if why:
+        print(f"[bench] multi-GPU launch failed: {why}", file=sys.stderr, flush=True)
+    return rc if (rc or out) else 1
+
+
+def init_ranks(torch, dist, a, world, rank, local_rank):
+    """device + process group of one rank.  RCCL ("nccl") is the backend; if its communicator cannot be created on
+    this node the CONTROL PLANE (barrier, max-over-ranks of the times: the replicated headline has no data-path
+    collective) falls back to gloo on a fresh port, and the line says so (config.control_backend)."""
+    from datetime import timedelta
+    # rehearsal knobs (one-GPU boxes only): REC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # REC_BENCH_BACKEND=gloo replaces RCCL, to exercise the multi-rank control flow without N GPUs
+    if os.environ.get("REC_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, this node exposes {torch.cuda.device_count()} GPU(s)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    backend = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("REC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
+                dist.barrier()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: RCCL process group failed ({type(e).__name__}: {str(e)[:200]}); control plane "
+                      "falls back to gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo (RCCL process group could not be created)"
+                port = int(os.environ.get("MASTER_PORT", "29500")) + 61
+                dist.init_process_group("gloo", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{port}", rank=rank,
+                                        world_size=world, timeout=timedelta(seconds=180))
+        else:
+            dist.init_process_group(backend, timeout=timedelta(seconds=180))
+    return dev, backend
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.side_leg:
+        sys.exit(launch_ranks(a))           # before any GPU call: the rank processes are fresh
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -343,39 +450,28 @@ def main():
     import torch.distributed as dist
 
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+        a.gpus = world                      # under a launcher the environment is authoritative
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # rehearsal knobs (one-GPU boxes only): REC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
-    # REC_BENCH_BACKEND=gloo replaces RCCL, to exercise the multi-rank control flow without N GPUs
-    if os.environ.get("REC_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("REC_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    dev, control_backend = init_ranks(torch, dist, a, world, rank, local_rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    transport_note = {}
+
     def build(wl, placement):
         a.placement = placement
         if placement == "rowshard" and world > 1 and "REC_SHARD_TRANSPORT" not in os.environ:
             # the library's own RCCL communicator first; if it cannot be created here, the same exchange over
-            # torch.distributed's collectives (every rank takes the same branch: the failure modes are per-node)
+            # torch.distributed's collectives (every rank takes the same branch: the failure modes are per-node) —
+            # and the line SAYS so (config.exchange.transport / .fallback)
             try:
                 return build_(wl)
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: C-ABI transport failed ({type(e).__name__}: {e}); using torch.distributed",
-                      file=sys.stderr, flush=True)
+                transport_note["fallback"] = f"C-ABI RCCL transport failed ({type(e).__name__}: {str(e)[:160]})"
+                print(f"[bench] rank {rank}: {transport_note['fallback']}; using torch.distributed", file=sys.stderr, flush=True)
                 os.environ["REC_SHARD_TRANSPORT"] = "torch"
         return build_(wl)
 
@@ -433,21 +529,18 @@ def main():
         return {"p10": round(s[len(s) // 10], 1), "p50": round(s[len(s) // 2], 1), "p90": round(s[(9 * len(s)) // 10], 1),
                 "first": round(us[0], 1), "mean_without_first": round(sum(rest) / len(rest), 1), "n": len(us)}
 
-    def measure(w):
-        spin(w["step"], a.spinup)
-        for i in range(a.warmup):
+    def measure(w, steps=None, warmup=None, spinup=None):
+        steps = a.steps if steps is None else steps
+        spin(w["step"], a.spinup if spinup is None else spinup)
+        for i in range(a.warmup if warmup is None else warmup):
             w["step"](i)
-        wall, dev_ms = timed(w["step"], a.steps)
+        wall, dev_ms = timed(w["step"], steps)
         if world > 1:
-            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
-        launch = stats(per_launch(w["step"], min(a.steps, 200)))
+        launch = stats(per_launch(w["step"], min(steps, 200)))
         return wall, dev_ms, launch
-
-    w = build(a.workload, a.placement)
-    head = {k: w[k] for k in ("units", "dtype", "workload", "config")}
-    wall, dev_ms, launch = measure(w)
 
     def roofline(w, dev_ms, launch):
         scale = 1e9 if w["unit"] == "GB/s" else 1e12
@@ -461,9 +554,15 @@ def main():
                 key: int(w["work"]), "ms_per_launch": round(dev_ms, 4), "launch_us": launch,
                 "frac_p50": round(ach50 / w["peak"], 4)}
 
+    w = build(a.workload, a.placement)
+    head = {k: w[k] for k in ("units", "dtype", "workload", "config")}
+    wall, dev_ms, launch = measure(w)
     roof = roofline(w, dev_ms, launch)
+    default_run = (world == 1 and not a.no_side and a.workload == "dlrm_fused" and w.get("sharded") is None
+                   and a.ids == "uniform")
 
-    # side measurements in the same run: the north-star gather kernel; at N > 1 the other placement
+    # ---- side measurements in the same run -------------------------------------------------------------------------
+    # the north-star gather kernel on the same tables
     gather_roof = None
     if not a.no_side and w.get("side_gather"):
         sg, sbytes = w["side_gather"]
@@ -478,6 +577,44 @@ def main():
                        "traffic": g_traffic, "traffic_source": g_src, "algorithmic_bytes_per_launch": sbytes,
                        "ms_per_launch": round(g_ms, 4), "launch_us": g_launch,
                        "samples_per_s": round(w["units"] / (g_ms * 1e-3), 1)}
+
+    def short(wx, steps, spinup=0.15):
+        """one of the other measurements of the default line: same contract (spin-up, warm-up, `steps` timed launches
+        between events, a per-launch pass), fewer steps"""
+        wl_wall, wl_ms, wl_launch = measure(wx, steps=steps, warmup=5, spinup=spinup)
+        r = roofline(wx, wl_ms, wl_launch)
+        return {"workload": wx["workload"], "value": round(wx["units"] * steps / wl_wall, 1), "unit": "samples/s",
+                "ms_per_step": round(wl_wall / steps * 1e3, 4), "steps": steps, "dtype": wx["dtype"],
+                "launch_us": {k: wl_launch[k] for k in ("p10", "p50", "p90")},
+                "roofline": {k: r[k] for k in r if k != "launch_us"}}
+
+    # the headline step on Zipf(1.05) ids (SURVEY §8d: both distributions are reported), same tables
+    zipf = None
+    if default_run:
+        try:
+            a.ids = "zipf"
+            zids = make_ids(torch, dev, a, w["units"], a.fields, w["shape_cfg"]["vocab"], rank)
+            a.ids = "uniform"
+            from recamd import ops
+            wz = dict(w, step=lambda i: ops.gather_pairwise_dot(w["group"], zids[i % NB], w["dense"], out=w["out_fused"]),
+                      shape_cfg=dict(w["shape_cfg"], ids="zipf"),
+                      workload=w["workload"] + ", Zipf(1.05) ids ((z - 1) mod V)")
+            zipf = short(wz, max(20, a.steps // 2))
+            shift = torch.arange(a.fields, device=dev, dtype=torch.int64)[None, :] * w["shape_cfg"]["vocab"]
+            zipf["unique_rows_per_launch"] = int(torch.unique(zids[0].to(torch.int64) + shift).numel())
+            del zids, wz
+        except Exception as e:  # noqa: BLE001
+            a.ids = "uniform"
+            zipf = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # the measured table placement beside the plain allocation of the headline
+    placed = None
+    if default_run and a.placed_candidates > 1 and a.arena_candidates <= 1:
+        try:
+            placed = placed_side(torch, dev, a, w, short)
+        except Exception as e:  # noqa: BLE001
+            placed = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     cpu_base = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.workload in ("dlrm_fused", "gather"):
         cpu_base = cpu_baseline(a, w)
@@ -490,6 +627,29 @@ def main():
             pcie = pcie_inclusive(torch, dev, a, w, spin)
         except Exception as e:  # noqa: BLE001
             pcie = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    exchange = None
+    if w.get("sharded") is not None:
+        exchange = w["sharded"].describe()
+        exchange.update(transport_note)
+
+    # BASELINE configs[2..4] under the same contract, each with its own roofline (the DLRM tables are released first)
+    configs = None
+    if default_run:
+        del w
+        torch.cuda.empty_cache()
+        configs = {}
+        for name in ("autoint", "din", "sasrec"):
+            try:
+                a.batch, a.vocab = 0, 0
+                wx = build_(name)
+                configs[name] = short(wx, 100)
+                configs[name]["config"] = wx["config"]
+                del wx
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                configs[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        w = None
 
     res = None
     if rank == 0:
@@ -510,19 +670,20 @@ def main():
                             "parallelism": f"dp{world}", "spinup_s": a.spinup}, **head["config"]),
             "roofline": roof,
         }
-        if w.get("sharded") is not None:
-            res["config"]["exchange"] = w["sharded"].describe()
-        if gather_roof is not None:
-            res["gather_roofline"] = gather_roof
-        if cpu_base is not None:
-            res["cpu_baseline"] = cpu_base
-        if pcie is not None:
-            res["pcie_inclusive"] = pcie
+        if world > 1:
+            res["config"]["control_backend"] = control_backend
+            res["config"]["launched_by"] = os.environ.get("REC_BENCH_LAUNCHED_BY", "external launcher (torch.distributed.run)")
+        if exchange is not None:
+            res["config"]["exchange"] = exchange
+        for key, val in (("gather_roofline", gather_roof), ("zipf", zipf), ("placed", placed), ("configs", configs),
+                         ("cpu_baseline", cpu_base), ("pcie_inclusive", pcie)):
+            if val is not None:
+                res[key] = val
 
     # At N > 1: release the parked child processes (spawn_side_leg) once every rank has finished the headline and
     # returned its tables to the allocator; ranks other than 0 only wait for their child to end.
     if side is not None:
-        del w
+        w = None
         torch.cuda.empty_cache()
         barrier()
         other = collect_side_leg(side[0], side[1], a.side_timeout)
@@ -533,6 +694,28 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def placed_side(torch, dev, a, w, short):
+    """`placed`: the headline step on the best of --placed-candidates arenas (recamd.ops.place_table_arena), the arena of
+    the headline being candidate 0.  What a deployment that can afford the probe gains; never `value`."""
+    from recamd import ops
+    F, D, V = a.fields, a.dim, w["shape_cfg"]["vocab"]
+    ids, dense, out = w["ids"], w["dense"], w["out_fused"]
+    out_g = torch.empty((w["units"], F * D), dtype=torch.float32, device=dev)
+    p_fused = lambda g, i: ops.gather_pairwise_dot(g, ids[i % NB], dense, out=out)  # noqa: E731
+    p_gather = lambda g, i: ops.gather_concat(g, ids[i % NB], out=out_g)  # noqa: E731
+    arena, info = ops.place_table_arena(F, V, D, dev, candidates=a.placed_candidates, probe=[p_fused, p_gather],
+                                        probe_name="[rec_gather_pairwise_dot_f32, rec_gather_concat_f32] steps of this "
+                                                   "workload, normalised times added", first=w["arena"])
+    if info.get("chosen", 0) != 0:
+        arena.copy_(w["arena"])                # same table contents as the headline
+    group = ops.TableGroup([arena[f] for f in range(F)])
+    wp = dict(w, step=lambda i: ops.gather_pairwise_dot(group, ids[i % NB], dense, out=out))
+    r = short(wp, max(20, a.steps // 2))
+    r.pop("workload")
+    r["table_placement"] = info
+    return r
 
 
 def pcie_inclusive(torch, dev, a, w, spin):

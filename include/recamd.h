@@ -103,7 +103,13 @@ int rec_pairwise_dot_f32(const float* x, int64_t B, int32_t n, int32_t D,
 /* Fused K1+K5: X rows 0..F-1 are gathered embedding rows (all tables must share dim D), and, when
  * `dense` != NULL, row F is dense[b, 0:D] (the bottom-MLP output; n = F+1).  Writes
  * out[b, 0:P] = strictly-lower-triangle dots and, if append_dense, out[b, P:P+D] = dense[b]
- * (mirrors tf.concat([sparse_part, dense_fea]) of src/ctr/dlrm/model.py:48). */
+ * (mirrors tf.concat([sparse_part, dense_fea]) of src/ctr/dlrm/model.py:48).
+ * PAD COLUMNS: with width = P (+ D), when `out` is 16-byte aligned AND out_stride % 4 == 0 the kernels store whole
+ * 16-byte groups, i.e. they also write ZEROS to out[b, width .. roundup4(width) - 1] (e.g. column 479 of a 479-wide
+ * result; out_stride >= roundup4(width) is then required).  A caller that places the result inside a wider row whose
+ * next column is live data must either start that data at a multiple of 4 columns, or pass an `out` / out_stride that
+ * does not satisfy the alignment condition (the tail group is then written with scalar stores, nothing past `width`).
+ * rec_pairwise_dot_f32 follows the same rule for its P columns. */
 int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t F,
                                 const void* ids, int32_t ids_dtype, int64_t ids_stride,
                                 const float* dense, int64_t dense_stride,
@@ -522,6 +528,21 @@ int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, int32_t* coun
 int rec_shard_dedup_bucket_i32(const int32_t* vids, int64_t n, int32_t G, int32_t* rep_table, int32_t* first,
                                int32_t* uniq, int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts,
                                void* workspace, void* stream);
+/* The general form (rec_shard_dedup_bucket_i32 = me -1, no cache, bases 0): where does each lookup read its row?
+ * The consumer kernels address ONE row space  [this rank's shard | hot-row replica cache | rows returned by the
+ * exchange]  (recamd/dist.py keeps it in one allocation so that a single table descriptor covers it):
+ *   vids[i] < 0                    uidx[i] = -1 (zero row)
+ *   me >= 0 and vids[i] % G == me  uidx[i] = vids[i] / G: read in place from this rank's shard, never sent
+ *   cache_slot[v] >= 0             uidx[i] = cache_base + cache_slot[v]: a replica of a hot remote row
+ *                                  (cache_slot: one int32 per virtual row, -1 = not cached; NULL = no cache)
+ *   otherwise                      uidx[i] = recv_base + position in the send list (de-duplicated as above)
+ * hot_count (one int32 per virtual row, or NULL) is incremented for every lookup of a remote row — the statistic a
+ * caller ranks rows by when it refills the cache.  stat (2 x uint64, or NULL) accumulates the number of lookups
+ * answered from the local shard and from the cache.  first[i] <= -2 encodes a direct row (-2 - row). */
+int rec_shard_resolve_i32(const int32_t* vids, int64_t n, int32_t G, int32_t me, int32_t* rep_table,
+                          const int32_t* cache_slot, int32_t* hot_count, int32_t cache_base, int32_t recv_base,
+                          uint64_t* stat, int32_t* first, int32_t* uniq, int32_t* perm, int32_t* uidx,
+                          int32_t* send_local, int32_t* counts, void* workspace, void* stream);
 /* out[i, :] = rows[perm[i], :]  (un-permute the returned rows), D floats per row */
 int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,
                            float* out, int64_t out_stride, void* stream);
@@ -557,6 +578,8 @@ int rec_comm_create_local(int32_t world, rec_comm** comms_out /* host array of `
 int rec_comm_destroy(rec_comm* comm);
 int32_t rec_comm_world(const rec_comm* comm);
 int32_t rec_comm_rank(const rec_comm* comm);
+/* "rccl" | "rccl (borrowed ncclComm_t)" | "in-process" | "caller-supplied": what a benchmark line reports as having run */
+const char* rec_comm_transport_name(const rec_comm* comm);
 /* gradient merge of replicated (dense) parameters: buf <- sum over ranks, in place (MirroredStrategy's all-reduce) */
 int rec_comm_allreduce_sum_f32(rec_comm* comm, float* buf, int64_t n, void* stream);
 
@@ -584,6 +607,19 @@ int rec_shard_plan_create(rec_comm* comm, int64_t max_ids, rec_shard_plan** out)
 int rec_shard_plan_destroy(rec_shard_plan* plan);
 int rec_shard_plan_ids(rec_shard_plan* plan, const int32_t* vids, int64_t n, int32_t* rep_table, void* workspace,
                        void* stream);
+/* rec_shard_plan_ids with the row space of rec_shard_resolve_i32: bypass_local = rows this rank owns are read in
+ * place (they are not sent to itself: the all-to-alls then carry remote rows only); NULL opts = rec_shard_plan_ids.
+ * Every call takes the stream it runs on: a pipelined caller plans and exchanges batch i+1 on a communication stream
+ * while batch i's consumer kernel runs on the compute stream (recamd/dist.py: events order the two). */
+typedef struct rec_shard_resolve_opts {
+  int32_t bypass_local;
+  const int32_t* cache_slot; /* device, or NULL */
+  int32_t* hot_count;        /* device, or NULL */
+  int32_t cache_base, recv_base;
+  uint64_t* stat;            /* device, 2 counters, or NULL */
+} rec_shard_resolve_opts;
+int rec_shard_plan_ids_ex(rec_shard_plan* plan, const int32_t* vids, int64_t n, int32_t* rep_table,
+                          const rec_shard_resolve_opts* opts, void* workspace, void* stream);
 int rec_shard_plan_finish(rec_shard_plan* plan, int64_t* n_unique /* host out */, int64_t* n_recv /* host out */);
 const int32_t* rec_shard_plan_uidx(const rec_shard_plan* plan);
 int rec_shard_exchange_ids(rec_shard_plan* plan, int32_t* recv_local, void* stream);

@@ -378,6 +378,7 @@ PYBIND11_MODULE(_C, m) {
   m.def("comm_destroy", [](ptr_t c) { check(rec_comm_destroy(P<rec_comm>(c)), "rec_comm_destroy"); });
   m.def("comm_world", [](ptr_t c) { return rec_comm_world(P<rec_comm>(c)); });
   m.def("comm_rank", [](ptr_t c) { return rec_comm_rank(P<rec_comm>(c)); });
+  m.def("comm_transport_name", [](ptr_t c) { return std::string(rec_comm_transport_name(P<rec_comm>(c))); });
   m.def("comm_allreduce_sum_f32", [](ptr_t c, ptr_t buf, int64_t n, ptr_t stream) {
     py::gil_scoped_release nogil;
     check(rec_comm_allreduce_sum_f32(P<rec_comm>(c), P<float>(buf), n, P<void>(stream)), "rec_comm_allreduce_sum_f32");
@@ -393,6 +394,25 @@ PYBIND11_MODULE(_C, m) {
     py::gil_scoped_release nogil;
     check(rec_shard_plan_ids(P<rec_shard_plan>(p), P<const int32_t>(vids), n, P<int32_t>(rep), P<void>(ws), P<void>(stream)),
           "rec_shard_plan_ids");
+  });
+  m.def("shard_plan_ids_ex", [](ptr_t p, ptr_t vids, int64_t n, ptr_t rep, int bypass_local, ptr_t cache_slot,
+                                ptr_t hot_count, int cache_base, int recv_base, ptr_t stat, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    rec_shard_resolve_opts o{bypass_local, P<const int32_t>(cache_slot), P<int32_t>(hot_count), cache_base, recv_base,
+                             P<uint64_t>(stat)};
+    check(rec_shard_plan_ids_ex(P<rec_shard_plan>(p), P<const int32_t>(vids), n, P<int32_t>(rep), &o, P<void>(ws),
+                                P<void>(stream)),
+          "rec_shard_plan_ids_ex");
+  });
+  m.def("shard_resolve_i32", [](ptr_t vids, int64_t n, int G, int me, ptr_t rep, ptr_t cache_slot, ptr_t hot_count,
+                                int cache_base, int recv_base, ptr_t stat, ptr_t first, ptr_t uniq, ptr_t perm, ptr_t uidx,
+                                ptr_t send_local, ptr_t counts, ptr_t ws, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_shard_resolve_i32(P<const int32_t>(vids), n, G, me, P<int32_t>(rep), P<const int32_t>(cache_slot),
+                                P<int32_t>(hot_count), cache_base, recv_base, P<uint64_t>(stat), P<int32_t>(first),
+                                P<int32_t>(uniq), P<int32_t>(perm), P<int32_t>(uidx), P<int32_t>(send_local),
+                                P<int32_t>(counts), P<void>(ws), P<void>(stream)),
+          "rec_shard_resolve_i32");
   });
   m.def("shard_plan_finish", [](ptr_t p) {
     int64_t nu = 0, nr = 0;

@@ -124,40 +124,80 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(const int32_t* __res
   }
 }
 
-// ---- exact per-lookup de-duplication (before the exchange) -----------------------------------------
-// rep[v] (one int32 per virtual row, INT32_MAX between calls) receives the smallest lookup index that asks for
-// row v: deterministic representative.  Representatives enter the send list, every lookup then reads the returned
-// row of its representative (uidx).  Out-of-range ids (negative after the caller's range check) are not sent at
-// all: uidx = -1, the consumer reads a zero row and raises the REQUESTER's oob flag.
-__global__ __launch_bounds__(256) void shard_first_kernel(const int32_t* __restrict__ vids, int64_t n,
+// ---- resolve: where does each lookup read its row? (before the exchange) ---------------------------------------
+// The consumers address ONE row space [this rank's shard | hot-row replica cache | rows returned by the exchange];
+// resolve turns a virtual id v into a row of that space:
+//   v < 0                         -> -1 (zero row; the consumer raises the REQUESTER's oob flag)
+//   me >= 0 and v % G == me       -> v / G: the row is read in place from this rank's shard (never sent to itself)
+//   cache_slot[v] >= 0            -> cache_base + cache_slot[v]: a replica of a hot remote row (exact copy)
+//   otherwise                     -> recv_base + position of the row in the buffer the exchange returns
+// Exact per-lookup de-duplication of the remote rows: rep[v] (one int32 per virtual row, INT32_MAX between calls)
+// receives the smallest lookup index that asks for row v — a deterministic representative.  Representatives enter
+// the send list, every lookup then reads the returned row of its representative.
+// `first[i]` carries the classification between the kernels: >= 0 representative lookup, -1 zero row,
+// <= -2 direct row (-2 - row).
+__device__ __forceinline__ bool is_local(int32_t v, int G, int me) { return me >= 0 && (v % G) == me; }
+
+__global__ __launch_bounds__(256) void shard_first_kernel(const int32_t* __restrict__ vids, int64_t n, int G, int me,
+                                                          const int32_t* __restrict__ cache_slot,
                                                           int32_t* __restrict__ rep) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int32_t v = vids[i];
-  if (v >= 0) atomicMin(&rep[v], (int32_t)i);
+  if (v < 0 || is_local(v, G, me)) return;
+  if (cache_slot && cache_slot[v] >= 0) return;
+  atomicMin(&rep[v], (int32_t)i);
 }
 
-__global__ __launch_bounds__(256) void shard_uniq_kernel(const int32_t* __restrict__ vids, int64_t n,
-                                                         const int32_t* __restrict__ rep, int32_t* __restrict__ first,
-                                                         int32_t* __restrict__ uniq) {
+__global__ __launch_bounds__(256) void shard_uniq_kernel(const int32_t* __restrict__ vids, int64_t n, int G, int me,
+                                                         const int32_t* __restrict__ rep,
+                                                         const int32_t* __restrict__ cache_slot,
+                                                         int32_t* __restrict__ hot_count, int32_t cache_base,
+                                                         unsigned long long* __restrict__ stat,
+                                                         int32_t* __restrict__ first, int32_t* __restrict__ uniq) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int32_t v = vids[i];
-  const int32_t f = v >= 0 ? (rep ? rep[v] : (int32_t)i) : -1;
-  first[i] = f;
-  uniq[i] = (f == (int32_t)i) ? v : kSkip;
+  int cls = 0;  // 1 local, 2 cached
+  if (i < n) {
+    const int32_t v = vids[i];
+    int32_t f = -1, u = kSkip;
+    if (v >= 0) {
+      if (is_local(v, G, me)) {
+        f = -2 - v / G;
+        cls = 1;
+      } else {
+        if (hot_count) atomicAdd(&hot_count[v], 1);  // integer atomics: order-independent
+        const int32_t cs = cache_slot ? cache_slot[v] : -1;
+        if (cs >= 0) {
+          f = -2 - (cache_base + cs);
+          cls = 2;
+        } else {
+          f = rep ? rep[v] : (int32_t)i;
+          u = (f == (int32_t)i) ? v : kSkip;
+        }
+      }
+    }
+    first[i] = f;
+    uniq[i] = u;
+  }
+  if (stat) {  // lookups served without the exchange, accumulated across calls (reporting only)
+    const unsigned long long ml = __ballot(cls == 1), mc = __ballot(cls == 2);
+    if ((threadIdx.x & 63) == 0) {
+      if (ml) atomicAdd(&stat[0], (unsigned long long)__popcll(ml));
+      if (mc) atomicAdd(&stat[1], (unsigned long long)__popcll(mc));
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void shard_uidx_kernel(const int32_t* __restrict__ vids, int64_t n,
                                                          const int32_t* __restrict__ first,
-                                                         const int32_t* __restrict__ perm, int32_t* __restrict__ rep,
-                                                         int32_t* __restrict__ uidx) {
+                                                         const int32_t* __restrict__ perm, int32_t recv_base,
+                                                         int32_t* __restrict__ rep, int32_t* __restrict__ uidx) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int32_t f = first[i];
-  uidx[i] = f >= 0 ? perm[f] : -1;
-  const int32_t v = vids[i];
-  if (rep && v >= 0) rep[v] = INT32_MAX;  // leave the table clean for the next call (duplicates write the same value)
+  uidx[i] = f >= 0 ? recv_base + perm[f] : (f == -1 ? -1 : -2 - f);
+  // leave the table clean for the next call (duplicates write the same value; only remote lookups touched it)
+  if (rep && f >= 0) rep[vids[i]] = INT32_MAX;
 }
 
 // a += b (the in-process test transport's all-reduce)
@@ -228,10 +268,11 @@ extern "C" int rec_shard_bucket_i32(const int32_t* ids, int64_t n, int32_t G, in
 }
 
 namespace rec {
-// device steps of rec_shard_plan_ids (shard_exchange.cpp): dedup (rep may be NULL) + stable bucketing of the
-// representatives.  ws_hist: rec_shard_bucket_workspace_bytes(n, G).
-int shard_plan_device(const int32_t* vids, int64_t n, int32_t G, int32_t* rep, int32_t* first, int32_t* uniq,
-                      int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts, void* ws_hist,
+// device steps of rec_shard_plan_ids / rec_shard_resolve_i32: classification + dedup (rep may be NULL) + stable
+// bucketing of the representatives.  ws_hist: rec_shard_bucket_workspace_bytes(n, G).
+int shard_plan_device(const int32_t* vids, int64_t n, int32_t G, int32_t me, int32_t* rep, const int32_t* cache_slot,
+                      int32_t* hot_count, int32_t cache_base, int32_t recv_base, uint64_t* stat, int32_t* first,
+                      int32_t* uniq, int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts, void* ws_hist,
                       hipStream_t st) {
   const char* who = "rec_shard_plan_ids";
   if (n == 0) {
@@ -241,15 +282,16 @@ int shard_plan_device(const int32_t* vids, int64_t n, int32_t G, int32_t* rep, i
   }
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (rep) {
-    hipLaunchKernelGGL(shard_first_kernel, dim3(nb), dim3(256), 0, st, vids, n, rep);
+    hipLaunchKernelGGL(shard_first_kernel, dim3(nb), dim3(256), 0, st, vids, n, G, me, cache_slot, rep);
     REC_CHECK_LAUNCH(who);
   }
-  hipLaunchKernelGGL(shard_uniq_kernel, dim3(nb), dim3(256), 0, st, vids, n, (const int32_t*)rep, first, uniq);
+  hipLaunchKernelGGL(shard_uniq_kernel, dim3(nb), dim3(256), 0, st, vids, n, G, me, (const int32_t*)rep, cache_slot,
+                     hot_count, cache_base, reinterpret_cast<unsigned long long*>(stat), first, uniq);
   REC_CHECK_LAUNCH(who);
   int rc = rec_shard_bucket_i32(uniq, n, G, counts, perm, send_local, ws_hist, st);
   if (rc != REC_OK) return rc;
   hipLaunchKernelGGL(shard_uidx_kernel, dim3(nb), dim3(256), 0, st, vids, n, (const int32_t*)first,
-                     (const int32_t*)perm, rep, uidx);
+                     (const int32_t*)perm, recv_base, rep, uidx);
   REC_CHECK_LAUNCH(who);
   return REC_OK;
 }
@@ -262,15 +304,27 @@ int shard_vec_add(float* a, const float* b, int64_t n, hipStream_t st) {
 }
 }  // namespace rec
 
+extern "C" int rec_shard_resolve_i32(const int32_t* vids, int64_t n, int32_t G, int32_t me, int32_t* rep_table,
+                                     const int32_t* cache_slot, int32_t* hot_count, int32_t cache_base,
+                                     int32_t recv_base, uint64_t* stat, int32_t* first, int32_t* uniq, int32_t* perm,
+                                     int32_t* uidx, int32_t* send_local, int32_t* counts, void* workspace,
+                                     void* stream) {
+  const char* who = "rec_shard_resolve_i32";
+  REC_CHECK_ARG(G >= 1 && G <= kMaxG && n >= 0 && n <= 0x7fffffffLL && me < G, REC_ESHAPE, "%s: n=%lld G=%d me=%d", who,
+                (long long)n, G, me);
+  REC_CHECK_ARG(cache_base >= 0 && recv_base >= 0, REC_ESHAPE, "%s: negative row base", who);
+  REC_CHECK_ARG(counts && workspace && (n == 0 || (vids && first && uniq && perm && uidx && send_local)), REC_EINVAL,
+                "%s: NULL pointer", who);
+  return rec::shard_plan_device(vids, n, G, me, rep_table, cache_slot, hot_count, cache_base, recv_base, stat, first,
+                                uniq, perm, uidx, send_local, counts, workspace, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int rec_shard_dedup_bucket_i32(const int32_t* vids, int64_t n, int32_t G, int32_t* rep_table, int32_t* first,
                                           int32_t* uniq, int32_t* perm, int32_t* uidx, int32_t* send_local,
                                           int32_t* counts, void* workspace, void* stream) {
-  const char* who = "rec_shard_dedup_bucket_i32";
-  REC_CHECK_ARG(G >= 1 && G <= kMaxG && n >= 0 && n <= 0x7fffffffLL, REC_ESHAPE, "%s: n=%lld G=%d", who, (long long)n, G);
-  REC_CHECK_ARG(counts && workspace && (n == 0 || (vids && first && uniq && perm && uidx && send_local)), REC_EINVAL,
-                "%s: NULL pointer", who);
-  return rec::shard_plan_device(vids, n, G, rep_table, first, uniq, perm, uidx, send_local, counts, workspace,
-                                reinterpret_cast<hipStream_t>(stream));
+  // every row through the exchange, rows counted from 0: resolve without a local shard, a cache or a row-space offset
+  return rec_shard_resolve_i32(vids, n, G, -1, rep_table, nullptr, nullptr, 0, 0, nullptr, first, uniq, perm, uidx,
+                               send_local, counts, workspace, stream);
 }
 
 extern "C" int rec_unpermute_rows_f32(const float* rows, const int32_t* perm, int64_t n, int32_t D,

@@ -28,8 +28,10 @@
 #include "common.h"
 
 namespace rec {
-int shard_plan_device(const int32_t* vids, int64_t n, int32_t G, int32_t* rep, int32_t* first, int32_t* uniq,
-                      int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts, void* ws_hist, hipStream_t st);
+int shard_plan_device(const int32_t* vids, int64_t n, int32_t G, int32_t me, int32_t* rep, const int32_t* cache_slot,
+                      int32_t* hot_count, int32_t cache_base, int32_t recv_base, uint64_t* stat, int32_t* first,
+                      int32_t* uniq, int32_t* perm, int32_t* uidx, int32_t* send_local, int32_t* counts, void* ws_hist,
+                      hipStream_t st);
 int shard_vec_add(float* a, const float* b, int64_t n, hipStream_t st);
 }  // namespace rec
 
@@ -373,6 +375,12 @@ extern "C" int rec_comm_destroy(rec_comm* c) {
 }
 
 extern "C" int32_t rec_comm_world(const rec_comm* c) { return c ? c->world : 0; }
+extern "C" const char* rec_comm_transport_name(const rec_comm* c) {
+  if (!c) return "none";
+  if (c->rccl_ctx) return c->rccl_ctx->owned ? "rccl" : "rccl (borrowed ncclComm_t)";
+  if (c->local_ctx) return "in-process";
+  return "caller-supplied";
+}
 extern "C" int32_t rec_comm_rank(const rec_comm* c) { return c ? c->rank : -1; }
 
 extern "C" int rec_comm_allreduce_sum_f32(rec_comm* c, float* buf, int64_t n, void* stream) {
@@ -453,8 +461,8 @@ extern "C" int rec_shard_plan_destroy(rec_shard_plan* p) {
   return REC_OK;
 }
 
-extern "C" int rec_shard_plan_ids(rec_shard_plan* p, const int32_t* vids, int64_t n, int32_t* rep_table, void* workspace,
-                                  void* stream) {
+extern "C" int rec_shard_plan_ids_ex(rec_shard_plan* p, const int32_t* vids, int64_t n, int32_t* rep_table,
+                                     const rec_shard_resolve_opts* opts, void* workspace, void* stream) {
   const char* who = "rec_shard_plan_ids";
   REC_CHECK_ARG(p && workspace && (vids || n == 0), REC_EINVAL, "%s: NULL pointer", who);
   REC_CHECK_ARG(n >= 0 && n <= p->max_ids, REC_ESHAPE, "%s: n=%lld exceeds the plan's max_ids=%lld", who, (long long)n,
@@ -464,8 +472,12 @@ extern "C" int rec_shard_plan_ids(rec_shard_plan* p, const int32_t* vids, int64_
   char* ws = static_cast<char*>(workspace);
   hipStream_t st = (hipStream_t)stream;
   auto I = [&](int64_t off) { return reinterpret_cast<int32_t*>(ws + off); };
-  int rc = shard_plan_device(vids, n, G, rep_table, I(L.first), I(L.uniq), I(L.perm), I(L.uidx), I(L.send_local),
-                             I(L.counts), ws + L.hist, st);
+  rec_shard_resolve_opts o{};
+  if (opts) o = *opts;
+  REC_CHECK_ARG(o.cache_base >= 0 && o.recv_base >= 0, REC_ESHAPE, "%s: negative row base", who);
+  int rc = shard_plan_device(vids, n, G, o.bypass_local ? p->comm->rank : -1, rep_table, o.cache_slot, o.hot_count,
+                             o.cache_base, o.recv_base, o.stat, I(L.first), I(L.uniq), I(L.perm), I(L.uidx),
+                             I(L.send_local), I(L.counts), ws + L.hist, st);
   if (rc != REC_OK) return rc;
   rc = p->comm->t.allgather_counts(p->comm->t.ctx, I(L.counts), I(L.matrix), stream);
   if (rc != REC_OK) return rc;
@@ -480,6 +492,11 @@ extern "C" int rec_shard_plan_ids(rec_shard_plan* p, const int32_t* vids, int64_
     REC_CHECK_ARG(e == hipSuccess, REC_EHIP, "%s: %s", who, hipGetErrorString(e));
   }
   return REC_OK;
+}
+
+extern "C" int rec_shard_plan_ids(rec_shard_plan* p, const int32_t* vids, int64_t n, int32_t* rep_table, void* workspace,
+                                  void* stream) {
+  return rec_shard_plan_ids_ex(p, vids, n, rep_table, nullptr, workspace, stream);
 }
 
 extern "C" int rec_shard_plan_finish(rec_shard_plan* p, int64_t* n_unique, int64_t* n_recv) {

@@ -23,7 +23,7 @@ class SASRec(Model):
                  user_dense_feature_columns=(), item_dense_feature_columns=(),
                  blocks=1, num_heads=1, att_hidden_unit=128, ffn_hidden_unit=128,
                  dnn_dropout=0., layer_norm_eps=1e-6, seq_len=10, neg_len=100, embed_reg=1e-6,
-                 last_row_only=True, sharded=None, shard_transport=None):
+                 last_row_only=True, sharded=None, shard_factory=None):
         super().__init__()
         from recamd.dist import ShardedTables, local_rows_of
         if isinstance(sharded, ShardedTables):
@@ -51,11 +51,16 @@ class SASRec(Model):
         if rw is not None and self._sharded is None:
             names = ('seq_item', 'pos_item', 'neg_item')
             feats = {f['feat']: f for f in self.user_sparse_feature_columns}
-            self._sharded = ShardedTables([self.user_embed_layers['embed_' + k].table for k in names],
-                                          [feats[k]['feat_num'] for k in names], rw[0], rw[1], transport=shard_transport)
-            for f, k in enumerate(names):  # the arena is the single source of truth: the layers' weights are views of it
-                layer = self.user_embed_layers['embed_' + k]
-                layer._w['embeddings'] = self._sharded.tables[f][:layer.input_dim]
+            # shard_factory: a ShardedTables subclass / factory with the same signature (tests simulate ranks with one)
+            self._sharded = (shard_factory or ShardedTables)([self.user_embed_layers['embed_' + k].table for k in names],
+                                                             [feats[k]['feat_num'] for k in names], rw[0], rw[1])
+
+            def point_layers(st):  # the row space is the single source of truth: the layers' weights are views of it
+                for f, k in enumerate(names):
+                    layer = self.user_embed_layers['embed_' + k]
+                    layer._w['embeddings'] = st.tables[f][:layer.input_dim]
+            point_layers(self._sharded)
+            self._sharded.on_rebuild.append(point_layers)   # receive slots sized by the first lookup: views move once
         self.item_embed_layers = {
             'embed_' + str(feat['feat']): self.track('item_embed_' + str(feat['feat']), nn.Embedding(
                 input_dim=feat['feat_num'], input_length=feat['feat_len'], output_dim=feat['embed_dim'],

@@ -77,7 +77,7 @@ class TableGroup:
 
 
 def place_table_arena(F: int, V: int, D: int, device, candidates: int = 4, probe=None, probe_launches: int = 12,
-                      probe_name: Optional[str] = None):
+                      probe_name: Optional[str] = None, first: Optional[torch.Tensor] = None):
     """(F, V, D) fp32 arena for F embedding tables, PLACED BY MEASUREMENT.
 
     The rate at which random rows of a multi-GB arena can be read depends on which physical memory the allocation
@@ -90,10 +90,17 @@ def place_table_arena(F: int, V: int, D: int, device, candidates: int = 4, probe
     tables will serve, i = launch counter; or a list of such probes, whose normalised times are added — is timed on
     each, the fastest is kept and the rest are freed.  Default probe:
     the materialised gather over uniform ids.  Returns (arena, info) with the probe time of every candidate — callers
-    report them (bench.py does).  candidates <= 1: one plain allocation, no probe."""
+    report them (bench.py does).  candidates <= 1: one plain allocation, no probe.  `first`: an existing (F, V, D)
+    arena that takes part as candidate 0 (its contents are kept).
+
+    Why allocations differ is only partly understood (profiles/r03_placement_probe.txt): the allocation call does not
+    matter (hipMalloc, contiguous, VMM chunks of 2 MiB .. 1 GiB show the same per-arena spread), the per-arena UTCL1
+    miss / multi-miss counters do — the page-table fragments the driver could build for the physical blocks it had.
+    There is no user-space control over that; this function measures instead, and bench.py keeps it out of its
+    headline (a plain allocation) and reports the placed result beside it."""
     dev = torch.device(device)
     if candidates <= 1:
-        return torch.empty((F, V, D), dtype=torch.float32, device=dev), {"candidates": 1}
+        return (first if first is not None else torch.empty((F, V, D), dtype=torch.float32, device=dev)), {"candidates": 1}
     if probe is None:
         gen = torch.Generator(device=dev).manual_seed(0)
         Bp = 65536
@@ -101,8 +108,8 @@ def place_table_arena(F: int, V: int, D: int, device, candidates: int = 4, probe
         pout = torch.empty((Bp, F * D), dtype=torch.float32, device=dev)
         probe = lambda g, i: gather_concat(g, pids[i % 4], out=pout)  # noqa: E731
         probe_name = probe_name or "rec_gather_concat_f32, %d x %d uniform ids" % (Bp, F)
-    arenas = []
-    for _ in range(candidates):
+    arenas = [] if first is None else [first]
+    for _ in range(candidates - len(arenas)):
         try:
             a = torch.empty((F, V, D), dtype=torch.float32, device=dev)
         except torch.OutOfMemoryError:

@@ -210,6 +210,9 @@ class BatchFeeder:
         queued: the GPU never idles on the host) -> its H2D + transforms overlap compute(i)."""
         nb = len(self)
         depth = len(self.slots)
+        # the scaler's statistics / the encoder's vocabulary were produced on the caller's stream (MinMaxScaler.fit
+        # launches asynchronously): the copy stream must not read them before they are written
+        self.copy_stream.wait_stream(torch.cuda.current_stream())
         sizes = {0: self._stage(self.slots[0], 0)} if nb else {}
         for i in range(nb):
             slot = self.slots[i % depth]

@@ -16,6 +16,7 @@ recipe for DLRM / DCN (which ship without a train script).
 Nothing here computes on the CPU; there is no autograd engine — every gradient is an explicit kernel."""
 from __future__ import annotations
 
+import math
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -558,6 +559,11 @@ def train_step(model, opt: Adam, state: TrainState, inputs, y_true, allreduce: O
     mean loss over the GLOBAL batch — what MirroredStrategy does (src/ctr/fm/train.py:43-45); BatchNormalization
     keeps per-replica batch statistics, as there."""
     dp = allreduce is not None and world > 1
+    if dp and opt.sparse:
+        # the lazy row-wise update touches (and clears) only the rows of THIS replica's ids; after the all-reduce the
+        # gradient buffers also hold the other replicas' rows, which would be neither applied nor cleared
+        raise NotImplementedError("Adam(sparse_embeddings=True) under data parallelism: the lazy row-wise update needs "
+                                  "the union of all replicas' ids; use the exact dense form (sparse_embeddings=False)")
     p, loss, grads = compute_gradients(model, state, inputs, y_true, 1.0 / world if dp else 1.0, seed=opt.step_no + 1)
     if dp:  # same order on every replica
         for k in sorted(grads):
@@ -622,6 +628,8 @@ class Trainer:
                 raise NotImplementedError(f"optimizer {optimizer!r}: the reference's train scripts all use Adam")
             optimizer = None
         self.opt = optimizer or Adam(self.model, learning_rate, l2=default_l2(self.model), sparse_embeddings=sparse_embeddings)
+        if self.opt.sparse and allreduce is not None and world > 1:
+            raise NotImplementedError("Adam(sparse_embeddings=True) is per-replica: not available with allreduce / world > 1")
         self.allreduce, self.world = allreduce, world
         return self
 
@@ -680,8 +688,8 @@ class Trainer:
         default_rng(seed + epoch).permutation (Keras' own shuffle is unseeded: not reproducible there either).
         y = None: a model whose loss is its own add_loss (SASRec, src/match/sasrec/model.py:93-95) — `loss` only."""
         n = self._len(x)
-        n_val = int(n * validation_split)
-        n_tr = n - n_val
+        n_tr = int(math.floor(n * (1.0 - validation_split)))     # Keras: split_at = floor(n * (1 - validation_split))
+        n_val = n - n_tr
         has_y = y is not None
         y_all = np.asarray(y, np.float32).reshape(-1) if has_y else None
         xt, xv = self._slice(x, slice(0, n_tr)), self._slice(x, slice(n_tr, n))

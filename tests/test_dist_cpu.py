@@ -1,10 +1,11 @@
 """N > 1 path of the row-sharded lookup and of the gradient merge, world_size 2 and 3 over gloo on the CPU.
 
-The transport logic (virtual ids, de-duplication contract, split sizes from the gathered count matrix, the two
-all-to-alls, reading the returned rows through uidx, the reverse all-to-all of the backward, the all-reduce) is the
-product code (recamd.dist.ShardedTables, transport 'torch'); the DEVICE steps are replaced by the numpy stand-ins of
-tests/shard_oracle.py (tests may use the oracle; the product has no CPU path).  Results must be bit-identical to the
-single-device gather+concat of the oracle."""
+The transport logic (virtual ids, the row space, split sizes from the gathered count matrix, the two all-to-alls,
+reading rows through uidx, local-shard bypass, the prefetch pipeline's bookkeeping, the hot-row replica cache, the
+reverse all-to-all of the backward, the all-reduce) is the product code (recamd.dist.ShardedTables, transport
+'torch'); the DEVICE steps are replaced by the numpy stand-ins of tests/shard_oracle.py::OracleShardedTables (tests
+may use the oracle; the product has no CPU path).  Results must be bit-identical to the single-device gather+concat
+of the oracle."""
 import os
 import socket
 
@@ -36,13 +37,13 @@ def _worker(rank, world, port, vocabs, D, B, seed, dedup, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import ref_numpy as ref
-        from recamd.dist import ShardedTables, shard_table
-        from tests.shard_oracle import OracleKernels
+        from recamd.dist import shard_table
+        from tests.shard_oracle import OracleShardedTables
         rng = np.random.default_rng(seed)  # every rank builds the same global tables
         tables = [rng.normal(size=(v, D)).astype(np.float32) for v in vocabs]
         ids = _batch(seed, rank, vocabs, B)
-        st = ShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in tables], vocabs, rank, world,
-                           kernels=OracleKernels(dedup), dedup=dedup)
+        st = OracleShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in tables], vocabs, rank, world,
+                                 dedup=dedup)
         flag = torch.zeros(1, dtype=torch.int32)
         t_ids = torch.from_numpy(ids)
         st.prefetch(t_ids)                                    # the pipelined form: plan first, look up later
@@ -53,6 +54,9 @@ def _worker(rank, world, port, vocabs, D, B, seed, dedup, ret):
         ok = ok and int(flag.item()) == int(has_oob) and st.stats["prefetch_hits"] == 1
         if dedup:
             ok = ok and st.stats["unique_sent"] < st.stats["ids"]
+        own = ((ids >= 0) & (ids < np.asarray(vocabs)[None, :]) & (ids % world == rank)).sum()
+        ok = ok and st.np_stats["local"] == int(own)           # rows this rank owns were read in place ...
+        ok = ok and plan.send_splits[rank] == 0                # ... and never sent to itself
 
         # backward: every rank's dy, summed at the owners == the oracle's dense gradient over ALL ranks' lookups
         dys = [np.random.default_rng(seed + 100 + r).normal(size=(B, len(vocabs) * D)).astype(np.float32) for r in range(world)]
@@ -109,8 +113,8 @@ def _sasrec_worker(rank, world, port, V, S, n_neg, B, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import ref_numpy as ref
-        from recamd.dist import ShardedTables, shard_table
-        from tests.shard_oracle import OracleKernels
+        from recamd.dist import shard_table
+        from tests.shard_oracle import OracleShardedTables
         d = 64
         rng = np.random.default_rng(7)                      # same tables and weights on every rank
         T = [rng.normal(size=(V, d)).astype(np.float32) * 0.3 for _ in range(3)]
@@ -124,8 +128,7 @@ def _sasrec_worker(rank, world, port, V, S, n_neg, B, ret):
         seq[np.arange(S)[None, :] < (S - lens)[:, None]] = 0
         seq, pos, neg = seq.astype(np.int32), r2.integers(0, V, size=(B, 1)).astype(np.int32), \
             r2.integers(0, V, size=(B, n_neg)).astype(np.int32)
-        st = ShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in T], [V] * 3, rank, world,
-                           kernels=OracleKernels(True), dedup=True)
+        st = OracleShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in T], [V] * 3, rank, world, dedup=True)
         ts, tp, tn = (torch.from_numpy(a) for a in (seq, pos, neg))
         vids = torch.cat([st.virtual_ids(0, ts, pad_id=0).reshape(-1), st.virtual_ids(1, tp).reshape(-1),
                           st.virtual_ids(2, tn).reshape(-1)])
@@ -180,8 +183,121 @@ def test_dedup_bucket_contract():
 
 
 def test_int64_ids_are_range_checked_before_narrowing():
-    from recamd.dist import ShardedTables
-    from tests.shard_oracle import OracleKernels
-    st = ShardedTables([torch.zeros((10, 4))], [10], 0, 1, kernels=OracleKernels())
+    from tests.shard_oracle import OracleShardedTables
+    st = OracleShardedTables([torch.zeros((10, 4))], [10], 0, 1)
     v = st._vids(torch.tensor([[3], [2 ** 32 + 3], [-7], [9]], dtype=torch.int64))
     assert v.tolist() == [3, -1, -1, 9]
+
+
+def test_resolve_contract_local_cached_remote():
+    """the numpy specification of rec_shard_resolve_i32: local rows in place, cached rows from the replica region,
+    the rest de-duplicated into the send list and read at recv_base + position"""
+    from tests.shard_oracle import resolve_np
+    G, me = 2, 1
+    v = np.array([5, -1, 8, 5, 4, 9, 8, 2, 9], np.int32)         # odd ids are local to rank 1
+    cache_slot = np.full(16, -1, np.int32)
+    cache_slot[8] = 3                                            # row 8 has a replica in cache entry 3
+    hot = np.zeros(16, np.int32)
+    counts, uidx, send_local, first, perm = resolve_np(v, G, me, True, cache_slot, cache_base=100, recv_base=1000,
+                                                       hot_count=hot)
+    # remote uncached: 4 (i=4), 2 (i=7) -> both owner 0, send order 4, 2 -> local rows 2, 1
+    assert counts.tolist() == [2, 0] and send_local.tolist() == [2, 1]
+    assert uidx.tolist() == [2, -1, 103, 2, 1000, 4, 103, 1001, 4]
+    assert hot[8] == 2 and hot[4] == 1 and hot[2] == 1 and hot[5] == 0 and hot[9] == 0   # remote lookups only
+
+
+def _pipeline_worker(rank, world, port, ret):
+    """the prefetch pipeline as bench.py drives it: plan two batches ahead, ids + rows one batch ahead, consume"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_numpy as ref
+        from recamd.dist import shard_table
+        from tests.shard_oracle import OracleShardedTables
+        vocabs, D, B, steps = [40, 17, 64], 8, 33, 7
+        rng = np.random.default_rng(5)
+        tables = [rng.normal(size=(v, D)).astype(np.float32) for v in vocabs]
+        st = OracleShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in tables], vocabs, rank, world,
+                                 max_ids=B * len(vocabs), slots=3)
+        batches = [torch.from_numpy(_batch(50 + k, rank, vocabs, B)) for k in range(steps + 2)]
+        ok = True
+        st.prefetch(batches[0], rows=True)
+        st.prefetch(batches[1])
+        for i in range(steps):
+            st.prefetch(batches[i + 2])                       # plan (i+2)
+            st.prefetch(batches[i + 1], rows=True)            # ids + rows of (i+1)
+            out = st.lookup(batches[i])                       # consume (i)
+            exp = ref.gather_concat(tables, batches[i].numpy(), oob="zero")
+            ok = ok and bool(np.array_equal(out.numpy().view(np.uint32), exp.view(np.uint32)))
+        ok = ok and st.stats["prefetch_hits"] == steps and st.stats["rows_prefetched"] == steps + 1
+        extra = [torch.from_numpy(_batch(999 + k, rank, vocabs, B)) for k in range(2)]
+        st.prefetch(extra[0])                                  # third lookup in flight: the last free slot
+        try:                                                   # a 4th must fail loudly, not overwrite a slot
+            st.prefetch(extra[1])
+            ok = False
+        except RuntimeError:
+            pass
+        ret[rank] = (ok, dict(st.stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prefetch_pipeline_gloo():
+    ret = _spawn(_pipeline_worker, 2)
+    assert all(ret.get(r) and ret[r][0] for r in range(2)), ret
+
+
+def _cache_worker(rank, world, port, ret):
+    """hot-row replica cache under Zipf ids: unique remote rows per step drop >= 5x, results stay bit-exact, a weight
+    write invalidates the replicas"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_numpy as ref
+        from recamd.dist import shard_table
+        from tests.shard_oracle import OracleShardedTables
+        F, V, D, B = 4, 2000, 8, 512
+        vocabs = [V] * F
+        rng = np.random.default_rng(11)
+        tables = [rng.normal(size=(V, D)).astype(np.float32) for _ in range(F)]
+
+        def zipf_batch(k):
+            z = np.random.default_rng(1000 * rank + k).zipf(1.4, size=(B, F))
+            return torch.from_numpy(((z - 1) % V).astype(np.int32))
+
+        def run(cache_rows):
+            OracleShardedTables.generation = 0
+            st = OracleShardedTables([shard_table(torch.from_numpy(t), rank, world) for t in tables], vocabs, rank, world,
+                                     max_ids=B * F, cache_rows=cache_rows, cache_refresh_every=4 if cache_rows else 0)
+            sent, ok = [], True
+            for k in range(32):
+                ids = zipf_batch(k)
+                before = st.stats["unique_sent"]
+                out = st.lookup(ids)
+                sent.append(st.stats["unique_sent"] - before)
+                ok = ok and bool(np.array_equal(out.numpy().view(np.uint32),
+                                                ref.gather_concat(tables, ids.numpy(), oob="zero").view(np.uint32)))
+            return st, sent, ok
+
+        _, sent_plain, ok0 = run(0)
+        st, sent_cached, ok1 = run(2048)
+        ok = ok0 and ok1 and st.stats["cache_refreshes"] == 7
+        steady_plain, steady_cached = sum(sent_plain[24:]), sum(sent_cached[24:])
+        ok = ok and steady_cached * 5 <= steady_plain and st.np_stats["cached"] > 0
+        # a weight write: the owners' rows change, the replicas must not be served any more
+        for f in range(F):
+            st.tables[f].mul_(2.0)
+        OracleShardedTables.generation += 1
+        ids = zipf_batch(99)
+        out = st.lookup(ids)
+        ok = ok and bool(np.array_equal(out.numpy(), 2.0 * ref.gather_concat(tables, ids.numpy(), oob="zero")))
+        ret[rank] = (ok, steady_plain, steady_cached)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hot_row_cache_gloo():
+    ret = _spawn(_cache_worker, 2)
+    assert all(ret.get(r) and ret[r][0] for r in range(2)), ret

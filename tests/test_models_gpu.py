@@ -322,11 +322,12 @@ def test_sasrec(dev, blocks, heads, last_row_only):
 @pytest.mark.parametrize("G", [1, 8])
 def test_sasrec_row_sharded_simulated_ranks(dev, G):
     """BASELINE configs[4] as stated: SASRec S=200, d=64 with the seq/pos/neg tables row-sharded (row % G) behind the
-    sharded lookup, G ranks simulated on one GPU (transport 'peers': each rank's requests are served from the owner's
+    sharded lookup, G ranks simulated on one GPU (tests/shard_oracle.py::PeersShardedTables: a rank's requests are served from the owner's
     shard, which is what the RCCL all-to-all pair delivers; the exchange itself is covered by tests/test_shard_gpu.py
     and tests/test_dist_cpu.py).  Every rank's logits equal the oracle's sasrec_forward on the UNSHARDED tables."""
     from match.sasrec.model import SASRec
     from recamd.dist import shard_table
+    from tests.shard_oracle import PeersShardedTables
     rng = np.random.default_rng(50 + G)
     V, S, n, B, d = 5000, 200, 100, 24, 64
     uf = [{'feat': 'seq_item', 'feat_num': V, 'feat_len': S, 'embed_dim': d},
@@ -345,7 +346,7 @@ def test_sasrec_row_sharded_simulated_ranks(dev, G):
     w = full.get_weights()
     tabs = {k: w[f'user_embed_{k}/embeddings'] for k in ('seq_item', 'pos_item', 'neg_item')}
     ranks = [SASRec(uf, [], blocks=1, num_heads=1, att_hidden_unit=d, seq_len=S, neg_len=n, sharded=(r, G),
-                    shard_transport="peers" if G > 1 else None) for r in range(G)]
+                    shard_factory=PeersShardedTables) for r in range(G)]
     if G > 1:
         for m in ranks:
             m._sharded.link_peers([x._sharded for x in ranks])

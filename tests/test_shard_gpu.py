@@ -49,13 +49,26 @@ def test_sharded_tables_world1_hip(dev):
     assert np.array_equal(out.view(np.uint32), ref.gather_concat(tables, ids, oob="zero").view(np.uint32))
 
 
+def _resolve_hip(dev, vids, G, me, rep, cache_slot, hot, cache_base, recv_base, stat):
+    from recamd._lib import C
+    n = len(vids)
+    t_v = torch.from_numpy(vids).to(dev)
+    i32 = lambda m: torch.empty(max(1, m), dtype=torch.int32, device=dev)  # noqa: E731
+    first, uniq, perm, uidx, send_local, counts = i32(n), i32(n), i32(n), i32(n), i32(n), i32(G)
+    ws = torch.empty(max(1, C.shard_bucket_workspace_bytes(n, G)), dtype=torch.uint8, device=dev)
+    ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    C.shard_resolve_i32(t_v.data_ptr(), n, G, me, ptr(rep), ptr(cache_slot), ptr(hot), cache_base, recv_base, ptr(stat),
+                        first.data_ptr(), uniq.data_ptr(), perm.data_ptr(), uidx.data_ptr(), send_local.data_ptr(),
+                        counts.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return counts.cpu().numpy(), uidx[:n].cpu().numpy(), send_local[:n].cpu().numpy()
+
+
 @pytest.mark.parametrize("n", [0, 1, 7, 1024, 1025, 50_003])
 @pytest.mark.parametrize("G", [1, 2, 8, 7])
 @pytest.mark.parametrize("dedup", [True, False])
 def test_dedup_bucket_matches_numpy_contract(dev, n, G, dedup):
-    """rec_shard_dedup_bucket_i32 == tests/shard_oracle.dedup_bucket_np, integer for integer, and the
-    representative table is left clean (all INT32_MAX) for the next call."""
-    from recamd.dist import HipKernels
+    """rec_shard_resolve_i32 without a local shard / cache (= rec_shard_dedup_bucket_i32) == tests/shard_oracle.
+    dedup_bucket_np, integer for integer, and the representative table is left clean (all INT32_MAX) for the next call."""
     from tests.shard_oracle import dedup_bucket_np
     rng = np.random.default_rng(n * 3 + G)
     R = 5000
@@ -64,13 +77,91 @@ def test_dedup_bucket_matches_numpy_contract(dev, n, G, dedup):
         vids[1] = -1
         vids[n - 1] = vids[0]
     rep = torch.full((R,), 2 ** 31 - 1, dtype=torch.int32, device=dev) if dedup else None
-    counts, uidx, send_local = HipKernels().dedup_bucket(torch.from_numpy(vids).to(dev), G, rep)
+    counts, uidx, send_local = _resolve_hip(dev, vids, G, -1, rep, None, None, 0, 0, None)
     e_counts, e_uidx, e_send, _, _ = dedup_bucket_np(vids, G, dedup)
-    assert np.array_equal(counts.cpu().numpy(), e_counts)
-    assert np.array_equal(uidx.cpu().numpy(), e_uidx)
-    assert np.array_equal(send_local.cpu().numpy()[:len(e_send)], e_send)
+    assert np.array_equal(counts, e_counts)
+    assert np.array_equal(uidx, e_uidx)
+    assert np.array_equal(send_local[:len(e_send)], e_send)
     if dedup:
         assert int((rep != 2 ** 31 - 1).sum().item()) == 0
+
+
+@pytest.mark.parametrize("n", [1, 1000, 70_001])
+@pytest.mark.parametrize("G,me", [(2, 0), (8, 5), (3, 2)])
+@pytest.mark.parametrize("cached", [False, True])
+def test_resolve_row_space_matches_numpy_contract(dev, n, G, me, cached):
+    """rec_shard_resolve_i32 with a local shard (rows read in place, never sent to itself), a replica cache and the
+    row-space offsets == tests/shard_oracle.resolve_np; hot counts and the local / cached statistics agree."""
+    from tests.shard_oracle import resolve_np
+    rng = np.random.default_rng(n + 13 * G + me)
+    R = 4000
+    vids = rng.integers(-1, R, size=n).astype(np.int32)
+    cs_np = np.full(R, -1, np.int32)
+    if cached:
+        hot_rows = rng.choice(R, size=300, replace=False)
+        cs_np[hot_rows] = np.arange(300, dtype=np.int32)
+    rep = torch.full((R,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+    cache_slot = torch.from_numpy(cs_np).to(dev) if cached else None
+    hot = torch.zeros(R, dtype=torch.int32, device=dev)
+    stat = torch.zeros(2, dtype=torch.int64, device=dev)
+    counts, uidx, send_local = _resolve_hip(dev, vids, G, me, rep, cache_slot, hot, 10_000, 20_000, stat)
+    hot_np = np.zeros(R, np.int32)
+    e_counts, e_uidx, e_send, _, _ = resolve_np(vids, G, me, True, cs_np if cached else None, 10_000, 20_000, hot_np)
+    assert np.array_equal(counts, e_counts) and counts[me] == 0
+    assert np.array_equal(uidx, e_uidx)
+    assert np.array_equal(send_local[:len(e_send)], e_send)
+    assert np.array_equal(hot.cpu().numpy(), hot_np)
+    u = e_uidx.astype(np.int64)
+    assert stat.tolist() == [int(((u >= 0) & (u < 10_000)).sum()), int(((u >= 10_000) & (u < 20_000)).sum())]
+    assert int((rep != 2 ** 31 - 1).sum().item()) == 0
+
+
+@pytest.mark.parametrize("cache_rows", [0, 512])
+def test_pipeline_bypass_cache_simulated_ranks(dev, cache_rows):
+    """The product's lookup pipeline on the real kernels and streams, G ranks simulated in one process
+    (tests/shard_oracle.py::PeersShardedTables replaces only the transport): plan two batches ahead, ids + rows one
+    batch ahead on the communication stream, consume on the compute stream — as bench.py drives it.  The fused gather +
+    pairwise dot and the gather + concat read the row space (local shard in place | replica cache | receive slot) and
+    must equal the unsharded kernels bit for bit."""
+    from recamd import ops
+    from recamd.dist import shard_table
+    from tests.shard_oracle import PeersShardedTables
+    G, F, D, B, V, steps = 4, 26, 128, 256, 3000, 9
+    rng = np.random.default_rng(17)
+    tables = [torch.from_numpy(rng.normal(size=(V, D)).astype(np.float32)).to(dev) for _ in range(F)]
+    full = ops.TableGroup(tables)
+    st = [PeersShardedTables([shard_table(t, r, G) for t in tables], [V] * F, r, G, max_ids=B * F, cache_rows=cache_rows,
+                             cache_refresh_every=3 if cache_rows else 0) for r in range(G)]
+    for s in st:
+        s.link_peers(st)
+    dense = torch.from_numpy(rng.normal(size=(B, D)).astype(np.float32)).to(dev)
+
+    def batch(r, k):
+        z = np.random.default_rng(100 * r + k).zipf(1.3, size=(B, F))
+        ids = ((z - 1) % V).astype(np.int32)
+        ids[0, 0] = -1 if k % 2 else V                    # an out-of-range id in every batch
+        return torch.from_numpy(ids).to(dev)
+    for r in range(G):
+        batches = [batch(r, k) for k in range(steps + 2)]
+        st[r].prefetch(batches[0], rows=True)
+        st[r].prefetch(batches[1])
+        for i in range(steps):
+            st[r].prefetch(batches[i + 2])
+            st[r].prefetch(batches[i + 1], rows=True)
+            flag = ops.new_oob_flag(dev)
+            if i % 2 == 0:
+                got = st[r].lookup_pairwise_dot(batches[i], dense, oob_flag=flag)
+                exp = ops.gather_pairwise_dot(full, batches[i], dense)
+            else:
+                got = st[r].lookup(batches[i], oob_flag=flag)
+                exp = ops.gather_concat(full, batches[i])
+            assert torch.equal(got.view(torch.int32), exp.view(torch.int32)), (r, i)
+            assert int(flag.item()) == 1
+        d = st[r].describe()
+        assert d["prefetch_hits"] == steps and d["rows_prefetched"] == steps + 1 and d["pipelined"]
+        assert d["local_lookups"] > 0 and d["unique_sent"] < d["ids"]
+        if cache_rows:
+            assert d["cache_refreshes"] >= 2 and d["cache_hits"] > 0
 
 
 @pytest.mark.parametrize("G", [2, 8])

@@ -321,13 +321,28 @@ def test_data_parallel_replicas_stay_identical(dev):
             assert close(wa[k], e, floor=1e-2), k
 
 
+def test_sparse_adam_refuses_data_parallel(dev):
+    """the lazy row-wise Adam updates (and clears) only this replica's rows; with merged gradients the other
+    replicas' rows would be neither applied nor cleared and the replicas would diverge — refused, not silently wrong."""
+    from recamd import train as tr
+    rng = np.random.default_rng(9)
+    m, okind, kw, inp, y = _setup("deepfm", dev, rng)
+    merge = lambda t: t  # noqa: E731
+    with pytest.raises(NotImplementedError):
+        tr.Trainer(m).compile(sparse_embeddings=True, allreduce=merge, world=2)
+    opt = tr.Adam(m, 1e-2, l2=tr.default_l2(m), sparse_embeddings=True)
+    with pytest.raises(NotImplementedError):
+        tr.train_step(m, opt, tr.TrainState(m), inp, y, allreduce=merge, world=2)
+    tr.train_step(m, opt, tr.TrainState(m), inp, y)            # a single replica: fine
+
+
 def test_fit_evaluate_early_stopping_checkpoint(dev, tmp_path):
     """compile / fit / evaluate as src/ctr/deep_fm/train.py:44-68 runs them, on seeded synthetic data: per-epoch loss
     and AUC equal the oracle loop's; EarlyStopping(patience=1, restore_best_weights=True) restores the best epoch's
     weights; a weights-only checkpoint round-trips."""
     from recamd import train as tr
     rng = np.random.default_rng(21)
-    m, okind, kw, inputs, y = _setup("deepfm", dev, rng, B=400, scale=0.05)
+    m, okind, kw, inputs, y = _setup("deepfm", dev, rng, B=403, scale=0.05)   # 403 * 0.2 is not an integer
     w_init = m.get_weights()                   # inference-mode BN must not saturate the sigmoid: sane moving statistics
     m.set_weights({k: (np.zeros_like(v) if k.endswith("moving_mean") else np.ones_like(v))
                    for k, v in w_init.items() if "moving_" in k})
@@ -339,8 +354,8 @@ def test_fit_evaluate_early_stopping_checkpoint(dev, tmp_path):
     hist = trainer.fit(inputs, y, batch_size=64, epochs=3, validation_split=0.2, callbacks=[es], shuffle=True, seed=3)
     # the oracle loop
     n = len(y)
-    n_val = int(n * 0.2)
-    n_tr = n - n_val
+    n_tr = int(np.floor(n * (1.0 - 0.2)))      # Keras: split_at = floor(n * (1 - validation_split)) -> 322 train / 81 val
+    assert n_tr == 322 and n - n_tr == 81 and int(n * 0.2) == 80      # (int(n * 0.2) would give 323 / 80)
     oo = rt.AdamOracle(lr=5e-3)
     sl = lambda idx: [inputs[0][idx], inputs[1][idx]]  # noqa: E731
     e_hist = {"loss": [], "auc": [], "val_loss": [], "val_auc": []}
