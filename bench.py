@@ -95,8 +95,12 @@ def parse():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--arena-candidates", type=int, default=1,
                     help="table arenas allocated and probed before one is kept for the HEADLINE (1 = a plain allocation)")
+    ap.add_argument("--arena-skip-gb", type=float, default=0.0,
+                    help="plain allocation: GiB of device memory held by a spacer while the tables are allocated, then freed "
+                         "(the tables then do not share the low end of a fresh process's memory with the runtime's own allocations)")
     ap.add_argument("--placed-candidates", type=int, default=6,
                     help="side measurement `placed`: the headline step on the best of this many arenas (0 = skip)")
+    ap.add_argument("--din-width", type=int, default=64, help="--workload din: table width (3 tables; BASELINE configs[3] = 64)")
     ap.add_argument("--cache-rows", type=int, default=0, help="rowshard: hot-row replicas per rank (0 = off)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-spawned N > 1 run: watchdog of the rank processes (s)")
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
@@ -133,8 +137,15 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
     gen = torch.Generator(device=dev).manual_seed(0)
     sharded = None
     placed = None
-    # ids, dense and result buffers are allocated BEFORE the tables: buffers that land in memory recycled from the freed
-    # arena candidates ran the gather 2 % slower (tools/exp/arena_drift.py)
+    # a plain allocation (the headline): the tables are the FIRST allocation of the process.  With placement by
+    # measurement the ids, dense and result buffers come first instead: buffers that land in memory recycled from the
+    # freed arena candidates ran the gather 2 % slower (tools/exp/arena_drift.py)
+    early_arena = None
+    if a.placement == "replicated" and a.arena_candidates <= 1 and os.environ.get("REC_BENCH_TABLES_LAST") != "1":
+        spacer = torch.empty(int(a.arena_skip_gb * 2 ** 30), dtype=torch.uint8, device=dev) if a.arena_skip_gb > 0 else None
+        early_arena = torch.empty((F, V, D), dtype=torch.float32, device=dev)
+        del spacer
+        torch.cuda.empty_cache()
     ids = make_ids(torch, dev, a, B, F, V, rank)
     dense = torch.rand((B, D), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
     # (B, 479) result with a 480-float (16-B aligned) row stride, as recamd.ops allocates it
@@ -147,7 +158,7 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
         p_gather = lambda g, i: ops.gather_concat(g, ids[i % NB], out=out_gather)  # noqa: E731
         # the headline run also reports the materialised gather on the same tables: both kernels are probed (they rank
         # allocations differently) and the sum of their normalised times decides
-        arena, placed = ops.place_table_arena(F, V, D, dev, candidates=a.arena_candidates,
+        arena, placed = ops.place_table_arena(F, V, D, dev, candidates=a.arena_candidates, first=early_arena,
                                               probe=[p_fused, p_gather] if fused else p_gather,
                                               probe_name="[rec_gather_pairwise_dot_f32, rec_gather_concat_f32] steps of this "
                                                          "workload, normalised times added" if fused
@@ -166,8 +177,13 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
     def pipelined(consume):
         # plan two batches ahead, ids + rows one batch ahead (communication stream), consume this one (compute stream):
         # the exchange of batch i+1 overlaps batch i's kernel, and the plan's count matrix is on the host before the
-        # exchange that needs it is issued
-        def step(i):
+        # exchange that needs it is issued.  The pipeline runs on its OWN batch counter: bench passes (spin-up, warm-up,
+        # timed, per-launch) each restart `i` at 0, the lookups in flight carry over from one pass to the next.
+        pos = [0]
+
+        def step(_i):
+            i = pos[0]
+            pos[0] += 1
             sharded.prefetch(ids[(i + 2) % NB])
             sharded.prefetch(ids[(i + 1) % NB], rows=True)
             consume(ids[i % NB])
@@ -193,11 +209,14 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
         w["config"]["table_placement"] = placed
     if fused:
         w.update(step=step_fused, work=bytes_fused,
-                 kernel="rec::pairdot_ring_kernel<27, true, true, 2, 4, 0, 15> (LDS-DMA ring + fp32 MFMA, write-through result stores: fused gather + "
-                        "pairwise dot)" if sharded is None else "row-sharded lookup (RCCL all-to-all pair) + pairwise dot",
+                 kernel=(("rec::pairdot_ring_kernel<27, true, true, 2, 4, 0, 15>" if (F, D) == (26, 128) else
+                          "rec::pairdot_ring_gen_kernel (D = %d, n = %d)" % (D, n)) +
+                         " (LDS-DMA ring + fp32 MFMA, write-through result stores: fused gather + pairwise dot)")
+                 if sharded is None else "row-sharded lookup (RCCL all-to-all pair) + pairwise dot",
                  pmc_key="pairdot_ring_kernel",
-                 workload="DLRM 26 sparse x 1M vocab x dim 128, batch 65536/GPU: fused embedding gather + pairwise-dot "
-                          "(BASELINE configs[1])",
+                 workload="DLRM %d sparse x %s vocab x dim %d, batch %d/GPU: fused embedding gather + pairwise-dot%s"
+                          % (F, "1M" if V == 1_000_000 else str(V), D, B,
+                             " (BASELINE configs[1])" if (B, F, V, D) == (65536, 26, 1_000_000, 128) else ""),
                  side_gather=(step_gather, bytes_gather) if sharded is None else None)
     else:
         w.update(step=step_gather, work=bytes_gather, kernel="rec::gather_uniform_kernel<32, 0>",
@@ -231,14 +250,16 @@ def wl_autoint(torch, dev, a, rank, world):
 def wl_din(torch, dev, a, rank, world):
     from recamd import ops
     B, T, V = a.batch or 8192, 100, a.vocab or 1_000_000
-    d = 192
+    Dt = a.din_width
+    ntab = 3 if Dt <= 64 else 2
+    d = ntab * Dt
     gen = torch.Generator(device=dev).manual_seed(4 + rank)
-    tabs = [torch.empty((V, 64), device=dev).uniform_(-0.05, 0.05, generator=gen) for _ in range(3)]
+    tabs = [torch.empty((V, Dt), device=dev).uniform_(-0.05, 0.05, generator=gen) for _ in range(ntab)]
     g = ops.TableGroup(tabs)
     ids, real_slots = [], 0
     for j in range(NB):
         lens = torch.randint(1, T + 1, (B,), device=dev, generator=gen)
-        x = torch.randint(1, V, (B, T, 3), device=dev, dtype=torch.int32, generator=gen)
+        x = torch.randint(1, V, (B, T, ntab), device=dev, dtype=torch.int32, generator=gen)
         x[torch.arange(T, device=dev)[None, :] < (T - lens)[:, None]] = 0   # pre-padding with id 0 (pad_sequences)
         ids.append(x)
         real_slots += int(lens.sum().item())
@@ -252,15 +273,16 @@ def wl_din(torch, dev, a, rank, world):
 
     # bytes the kernel needs: ids of all T slots, rows of the REAL slots only (padded slots carry softmax weight
     # exactly 0 and are not fetched), q in, pooled row out
-    need = B * (T * 3 * 4 + 2 * d * 4) + (real_slots / NB) * d * 4
+    need = B * (T * ntab * 4 + 2 * d * 4) + (real_slots / NB) * d * 4
     return {"step": step, "units": B, "work": need, "dtype": "f32", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "kernel": "rec::din_gather_pool_grp_kernel<0, 3> (fused history lookup + attention pooling, one 16-lane group per slot)",
+            "kernel": "rec::din_gather_pool_grp_kernel<0, %d, %d> (fused history lookup + attention pooling, one %d-lane group per slot)" % (ntab, Dt // 4, Dt // 4),
             "pmc_key": "din_gather_pool_grp_kernel",
-            "workload": "DIN var-len user history (max 100) attention pooling, batch 8192 (BASELINE configs[3])",
+            "workload": "DIN var-len user history (max 100) attention pooling, batch 8192" +
+                        (" (BASELINE configs[3])" if (Dt, B, T) == (64, 8192, 100) else ", %d tables x width %d" % (ntab, Dt)),
             "config": {"batch_per_gpu": B, "global_batch": B * world, "maxlen": T, "d": d, "vocab_per_table": V,
                        "mean_real_slots": round(real_slots / NB / B, 2),
                        "bytes_note": "rows of real (non-pad) history slots only + all ids + q + out"},
-            "side_gather": None, "shape_cfg": {"workload": "din", "batch": B, "vocab": V, "ids": a.ids}}
+            "side_gather": None, "shape_cfg": {"workload": "din", "batch": B, "vocab": V, "ids": a.ids, "width": Dt}}
 
 
 def wl_sasrec(torch, dev, a, rank, world):

@@ -393,8 +393,10 @@ __global__ __launch_bounds__(256) void din_gather_pool_lds_kernel(const float* _
 // (one load instruction per table covers four slots: 1 KiB); a score is a 16-lane reduction (four DPP steps inside one
 // row), the four groups keep independent online-softmax states that are merged once at the end, the rescale happens once
 // per batch (batch maximum first), and exp is v_exp_f32 on log2(e)-scaled scores: ~14 VALU per slot.
-template <int IDS_F32, int NTAB>
-__global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_kernel(const float* __restrict__ q, DinTables tb,
+// Round 3: the lanes per row are a template parameter — LPR = Dt / 4 in {4, 8, 16, 32} (tables 16 / 32 / 64 / 128 wide), 64 / LPR
+// lane groups per wave, one slot each; Dt = 64 (LPR 16) is the BASELINE configs[3] instantiation and compiles as before.
+template <int IDS_F32, int NTAB, int LPR = 16>
+__global__ __launch_bounds__(256, (NTAB * LPR <= 48 ? 4 : 1)) void din_gather_pool_grp_kernel(const float* __restrict__ q, DinTables tb,
                                                                   const void* __restrict__ ids,
                                                                   const float* __restrict__ mask, int mask_mode,
                                                                   const float* __restrict__ W,
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
 #ifndef REC_DIN_U
 #define REC_DIN_U 2
 #endif
-  constexpr int Dt = 64, d = NTAB * Dt, U = REC_DIN_U;
+  constexpr int Dt = LPR * 4, d = NTAB * Dt, U = REC_DIN_U, NG = 64 / LPR;   // NG lane groups = slots per load step
   constexpr float kLog2e = 1.4426950408889634f;
   extern __shared__ int32_t din_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
   if (b >= B) return;
   int32_t* sid = din_lds + (size_t)w * T * (NTAB + 1);   // [T][NTAB] ids of the sample
   int32_t* slots = sid + (size_t)T * NTAB;                // [<= T] slots to fetch, in order; bit 31 = padded slot
-  const int sub = lane & 15, grp = lane >> 4;
+  const int sub = lane % LPR, grp = lane / LPR;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   const int64_t idbase = b * (int64_t)T * NTAB;
   const int nid = T * NTAB;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
     cpart += (cw.x + cw.y) + (cw.z + cw.w);
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) cpart += __shfl_xor(cpart, o, 64);   // every group holds all 16 x NTAB pieces
+  for (int o = LPR / 2; o > 0; o >>= 1) cpart += __shfl_xor(cpart, o, 64);   // every group holds all LPR x NTAB pieces
   const float c0 = cpart + bias[0];
   const float al = alpha ? alpha[0] : 0.f;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // batch = U steps of 4 slots; slot index of (step e, group g) = i0 + 4 e + g; indices past the end re-read the last
+  // batch = U steps of NG slots; slot index of (step e, group g) = i0 + NG e + g; indices past the end re-read the last
   // listed slot (a cache hit) and enter the softmax with the logit -inf
   // A/B builds (tools/exp/din_ab.sh, configs[3], same box): SKIP = lane groups without a slot issue nothing, NT =
   // streaming row loads.  SKIP 0 / NT 0 (shipped) 66.9-67.1 us; NT alone 71.0; SKIP (with or without NT) 99-101 us — the
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
     constexpr bool NTV = decltype(nt_tag)::value;
 #pragma unroll
     for (int e = 0; e < U; ++e) {
-      const int i = i0 + 4 * e + grp;
+      const int i = i0 + NG * e + grp;
 #if REC_DIN_SKIP
       // a lane group without a slot issues nothing (its rows enter the softmax with weight 0 whatever kr holds, but NaN
       // bits would survive the multiply by 0: zeros).  With streaming loads a clamped re-read of the last slot is an
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
   };
   auto load_batch = [&](int i0, f32x4 (&kr)[U][NTAB]) {
 #if REC_DIN_NT == 2
-    if (i0 + 4 * U <= n) load_batch_p(i0, kr, std::true_type{});
+    if (i0 + NG * U <= n) load_batch_p(i0, kr, std::true_type{});
     else load_batch_p(i0, kr, std::false_type{});
 #elif REC_DIN_NT == 1
     load_batch_p(i0, kr, std::true_type{});
@@ -535,14 +537,14 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
     float mb = m;
 #pragma unroll
     for (int e = 0; e < U; ++e) {
-      const int i = i0 + 4 * e + grp;
+      const int i = i0 + NG * e + grp;
       // the tables' products are chained as packed FMAs first, ONE horizontal sum afterwards (was: one per table)
       f32x4 pr = kr[e][0] * u[0];
 #pragma unroll
       for (int tt = 1; tt < NTAB; ++tt) pr = __builtin_elementwise_fma(kr[e][tt], u[tt], pr);
       float dsum = (pr.x + pr.y) + (pr.z + pr.w);
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
+      for (int o = LPR / 2; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
       float sv = act_apply(dsum + c0, act, al);
       if (slots[i < n ? i : n - 1] < 0) sv = kNegPad;
       s[e] = i < n ? sv * kLog2e : -INFINITY;
@@ -564,15 +566,15 @@ __global__ __launch_bounds__(256, (NTAB <= 3 ? 4 : 1)) void din_gather_pool_grp_
   };
   f32x4 ka[U][NTAB], kb[U][NTAB];
   load_batch(0, ka);
-  for (int i0 = 0; i0 < n; i0 += 8 * U) {
-    load_batch(i0 + 4 * U, kb);
+  for (int i0 = 0; i0 < n; i0 += 2 * NG * U) {
+    load_batch(i0 + NG * U, kb);
     reduce_batch(i0, ka);
-    load_batch(i0 + 8 * U, ka);
-    if (i0 + 4 * U < n) reduce_batch(i0 + 4 * U, kb);
+    load_batch(i0 + 2 * NG * U, ka);
+    if (i0 + NG * U < n) reduce_batch(i0 + NG * U, kb);
   }
-  // merge the four group states
+  // merge the group states
 #pragma unroll
-  for (int o = 16; o < 64; o <<= 1) {
+  for (int o = LPR; o < 64; o <<= 1) {
     const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
     const float mn = fmaxf(m, m2);
     const float s1 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
@@ -858,21 +860,31 @@ extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc
     const char* e = getenv("REC_DIN_IMPL");
     return !(e && (e[0] == 's' || e[0] == 'l'));
   }();
-  if (grp_ok && Dt == 64 && n_tab <= 4 && lds <= 48 * 1024) {
-#define REC_DIN_GRP(IDF_, NT_)                                                                                        \
-  hipLaunchKernelGGL((din_gather_pool_grp_kernel<IDF_, NT_>), grid, block, lds, st, q, tb, ids, mask, mode, W, bias,  \
+  // rows of 16 / 32 / 64 / 128 floats (4 / 8 / 16 / 32 lanes x 16 B): one lane group per history slot
+  // (din_gather_pool_grp_kernel; 64 is the BASELINE configs[3] width).  Register budget: NTAB x LPR <= 64 (d <= 256)
+  if (grp_ok && (Dt == 64 || Dt == 32 || Dt == 16 || Dt == 128) && n_tab <= 4 && n_tab * Dt <= 256 && lds <= 48 * 1024) {
+#define REC_DIN_GRP(IDF_, NT_, LPR_)                                                                                      \
+  hipLaunchKernelGGL((din_gather_pool_grp_kernel<IDF_, NT_, LPR_>), grid, block, lds, st, q, tb, ids, mask, mode, W, bias, \
                      alpha, act, B, T, out, oob_flag)
-    if (ids_dtype == REC_IDS_F32) {
-      if (n_tab == 1) REC_DIN_GRP(1, 1);
-      else if (n_tab == 2) REC_DIN_GRP(1, 2);
-      else if (n_tab == 3) REC_DIN_GRP(1, 3);
-      else REC_DIN_GRP(1, 4);
-    } else {
-      if (n_tab == 1) REC_DIN_GRP(0, 1);
-      else if (n_tab == 2) REC_DIN_GRP(0, 2);
-      else if (n_tab == 3) REC_DIN_GRP(0, 3);
-      else REC_DIN_GRP(0, 4);
+#define REC_DIN_GRP_NT(IDF_, LPR_)             \
+  if (n_tab == 1) REC_DIN_GRP(IDF_, 1, LPR_);  \
+  else if (n_tab == 2) REC_DIN_GRP(IDF_, 2, LPR_); \
+  else if (n_tab == 3) REC_DIN_GRP(IDF_, 3, LPR_); \
+  else REC_DIN_GRP(IDF_, 4, LPR_)
+    if (Dt == 64) {
+      if (ids_dtype == REC_IDS_F32) { REC_DIN_GRP_NT(1, 16); } else { REC_DIN_GRP_NT(0, 16); }
+    } else if (Dt == 32) {
+      if (ids_dtype == REC_IDS_F32) { REC_DIN_GRP_NT(1, 8); } else { REC_DIN_GRP_NT(0, 8); }
+    } else if (Dt == 16) {
+      if (ids_dtype == REC_IDS_F32) { REC_DIN_GRP_NT(1, 4); } else { REC_DIN_GRP_NT(0, 4); }
+    } else {  // 128-wide: at most two tables (d <= 256)
+      if (ids_dtype == REC_IDS_F32) {
+        if (n_tab == 1) REC_DIN_GRP(1, 1, 32); else REC_DIN_GRP(1, 2, 32);
+      } else {
+        if (n_tab == 1) REC_DIN_GRP(0, 1, 32); else REC_DIN_GRP(0, 2, 32);
+      }
     }
+#undef REC_DIN_GRP_NT
 #undef REC_DIN_GRP
     REC_CHECK_LAUNCH(who);
     return REC_OK;

@@ -340,6 +340,10 @@ int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const 
 bool pairdot128_ring_dispatch(const TableSet& ts, int F, bool has_dense, int ids_f32, const void* ids,
                               int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
                               int64_t out_stride, int append_dense, int* oob, hipStream_t st);
+// the same transport for the shapes around it: D in {64, 128, 256}, 17 <= n <= 32 (pairwise_dot_ring_gen.hip)
+bool pairdot_ring_gen_dispatch(const TableSet& ts, int F, int D, bool has_dense, int ids_f32, const void* ids,
+                               int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
+                               int64_t out_stride, int append_dense, int* oob, hipStream_t st);
 static bool use_ring() {
   static const bool on = [] {
     const char* e = getenv("REC_PAIRDOT_IMPL");
@@ -447,6 +451,11 @@ extern "C" int rec_gather_pairwise_dot_f32(const rec_table_desc* tables, int32_t
   if (D == 128 && use_ring() &&
       pairdot128_ring_dispatch(ts, F, dense != nullptr, ids_dtype == REC_IDS_F32, ids, ids_stride, dense,
                                dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
+    REC_CHECK_LAUNCH(who);
+    return REC_OK;
+  }
+  if (use_ring() && pairdot_ring_gen_dispatch(ts, F, D, dense != nullptr, ids_dtype == REC_IDS_F32, ids, ids_stride, dense,
+                                              dense_stride, B, out, out_stride, append_dense, oob_flag, st)) {
     REC_CHECK_LAUNCH(who);
     return REC_OK;
   }

@@ -20,3 +20,21 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """parity margins of this session (tests/util.py::MARGINS) -> gpurun_out/parity_margins.json"""
+    try:
+        from tests.util import MARGINS
+    except Exception:  # noqa: BLE001
+        return
+    if not MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    worst = sorted(MARGINS.items(), key=lambda kv: -kv[1]["used"])
+    with open(os.path.join(out, "parity_margins.json"), "w") as f:
+        json.dump({"note": "used = max over the test's checks of err / bound (1.0 = at the tolerance); tests/util.py",
+                   "tests": len(MARGINS), "worst": [{"test": k, **v} for k, v in worst[:25]],
+                   "all": {k: v for k, v in sorted(MARGINS.items())}}, f, indent=1)

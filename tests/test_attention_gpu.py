@@ -146,7 +146,9 @@ def test_mha_rowmask(dev, B, Sq, Sk, dm, H):
                 assert close(out[b, i], mean_v[b])
 
 
-@pytest.mark.parametrize("B,T_,n_tab,Dt", [(33, 100, 3, 64), (7, 10, 1, 16), (20, 37, 4, 32), (5, 3, 2, 128)])
+@pytest.mark.parametrize("B,T_,n_tab,Dt", [(33, 100, 3, 64), (7, 10, 1, 16), (20, 37, 4, 32), (5, 3, 2, 128),
+                                           (41, 100, 3, 32), (19, 77, 2, 128), (64, 100, 4, 16), (9, 130, 1, 128),
+                                           (6, 20, 3, 8)])      # widths 16 / 32 / 64 / 128: the lane-group kernel
 @pytest.mark.parametrize("mask_mode", ["ids", "tensor", "none"])
 def test_gather_din_attention_pool_fused(dev, B, T_, n_tab, Dt, mask_mode):
     """Fused history gather + pooling == oracle gather followed by the oracle AttentionLayer."""

@@ -102,7 +102,7 @@ def test_golden_sasrec(dev):
         f'{p}/ffn/conv2/bias': z["b0_b2"], f'{p}/layernorm1/gamma': z["b0_ln1_g"], f'{p}/layernorm1/beta': z["b0_ln1_b"],
         f'{p}/layernorm2/gamma': z["b0_ln2_g"], f'{p}/layernorm2/beta': z["b0_ln2_b"]})
     out = m([z["seq"], z["pos"], z["neg"]]).cpu().numpy()
-    assert close(out, z["expected"], 2e-5)
+    assert close(out, z["expected"], 1e-5)
 
 
 def test_golden_dcn(dev):

@@ -313,7 +313,7 @@ def test_sasrec(dev, blocks, heads, last_row_only):
     logits = m([seq, pos, neg]).cpu().numpy()
     exp, loss = ref.sasrec_forward(seq, pos, neg, w['user_embed_seq_item/embeddings'], w['user_embed_pos_item/embeddings'],
                                    w['user_embed_neg_item/embeddings'], [_sasrec_params(w, i) for i in range(blocks)], heads)
-    assert close(logits, exp, 2e-5)
+    assert close(logits, exp, 1e-5)
     assert abs(float(m.losses[0]) - loss) <= 1e-5 * max(1.0, abs(loss))
     # KAT: an all-zero sequence gives logits exactly 0.0
     assert np.all(logits[0] == 0.0)
@@ -361,7 +361,7 @@ def test_sasrec_row_sharded_simulated_ranks(dev, G):
         logits = ranks[r]([seq, pos, neg]).cpu().numpy()
         exp, loss = ref.sasrec_forward(seq, pos, neg, tabs['seq_item'], tabs['pos_item'], tabs['neg_item'],
                                        [_sasrec_params(w, 0)], 1)
-        assert close(logits, exp, 2e-5)
+        assert close(logits, exp, 1e-5)
         assert abs(float(ranks[r].losses[0]) - loss) <= 1e-5 * max(1.0, abs(loss))
         if G > 1:
             st = ranks[r]._sharded.describe()

@@ -188,3 +188,69 @@ def test_ring_kernel_order_kat_and_nonfinite(dev):
     assert np.array_equal(np.isinf(out[:, :351]), np.isinf(exp))
     fin = np.isfinite(exp)
     assert np.array_equal(out[:, :351][fin], exp[fin])
+
+
+# ---- the generalised ring kernel: D in {64, 128, 256}, 17 <= n <= 32 (pairwise_dot_ring_gen.hip) -----------------
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("F,has_dense,append", [(16, True, True), (17, False, False), (19, True, False), (23, True, True),
+                                                (26, False, False), (26, True, True), (28, True, True), (31, True, True),
+                                                (32, False, False)])
+@pytest.mark.parametrize("B", [1, 5, 1025, 4100])
+def test_ring_gen_kernel_bit_level(dev, D, F, has_dense, append, B):
+    """every (D, n) the generalised LDS-ring kernel serves: results within the kernel-level tolerance of the fp64 oracle
+    AND bit-identical to the documented fmaf chain (units of 64 / 128 columns, the two halves of D = 256 in sequence);
+    out-of-range ids read as zero rows and raise the flag; the dense row is appended bit-exactly; pad column zeroed."""
+    from recamd import ops
+    from tests.util import ring_order
+    if D == 128 and F == 26 and has_dense:
+        pytest.skip("the tuned 27 x 128 instantiation: test_ring_kernel_* above")
+    rng = np.random.default_rng(D * 1000 + F * 10 + B)
+    V = 41
+    n = F + (1 if has_dense else 0)
+    P = n * (n - 1) // 2
+    tables = [rng.normal(size=(V + f, D)).astype(np.float32) for f in range(F)]
+    ids = np.stack([rng.integers(0, V + f, size=B) for f in range(F)], axis=1).astype(np.int32)
+    if B >= 5:
+        ids[3, F - 1] = -1
+        ids[B - 1, 0] = V
+    dense = rng.normal(size=(B, D)).astype(np.float32) if has_dense else None
+    g = ops.TableGroup([torch.from_numpy(t).to(dev) for t in tables])
+    flag = ops.new_oob_flag(dev)
+    out = ops.gather_pairwise_dot(g, torch.from_numpy(ids).to(dev), None if dense is None else torch.from_numpy(dense).to(dev),
+                                  append_dense=append, oob_flag=flag)
+    width = P + (D if append else 0)
+    padded = out.as_strided((B, (width + 3) // 4 * 4), (out.stride(0), 1)).cpu().numpy()
+    out = out.cpu().numpy()
+    rows = ref.gather_concat(tables, ids, oob="zero").reshape(B, F, D)
+    X = rows if dense is None else np.concatenate([rows, dense[:, None, :]], axis=1)
+    assert out.shape == (B, width)
+    assert close_dot(out[:, :P], X)
+    chain = fmaf_chain_dot(X, ring_order(D))
+    same = out[:, :P].view(np.uint32) == chain.view(np.uint32)
+    assert same.mean() > 0.9999, f"only {same.mean():.6f} of the dots are bit-identical to the fmaf chain"
+    assert np.all(np.abs(out[:, :P] - chain) <= 2 * np.spacing(np.abs(chain)))
+    if append:
+        assert np.array_equal(out[:, P:].view(np.uint32), dense.view(np.uint32))
+    assert np.all(padded[:, width:] == 0.0)
+    assert int(flag.item()) == (1 if B >= 5 else 0)
+
+
+@pytest.mark.parametrize("D,F", [(64, 26), (256, 26), (128, 20)])
+def test_ring_gen_kernel_relaunch_is_bit_identical_and_matches_the_register_tiled_kernel(dev, D, F):
+    """size-independent properties at a batch that gives every persistent wave several samples: two launches agree bit
+    for bit, and the unfused path (materialised gather -> rec_pairwise_dot_f32) agrees within the tolerance"""
+    from recamd import ops
+    rng = np.random.default_rng(D + F)
+    B, V = 20_000, 3000
+    tables = [torch.from_numpy(rng.normal(size=(V, D)).astype(np.float32)).to(dev) for _ in range(F)]
+    ids = torch.from_numpy(rng.integers(0, V, size=(B, F)).astype(np.int32)).to(dev)
+    dense = torch.from_numpy(rng.normal(size=(B, D)).astype(np.float32)).to(dev)
+    g = ops.TableGroup(tables)
+    a = ops.gather_pairwise_dot(g, ids, dense)
+    b = ops.gather_pairwise_dot(g, ids, dense)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    X = torch.cat([ops.gather_concat(g, ids).view(B, F, D), dense[:, None, :]], dim=1).contiguous()
+    P = (F + 1) * F // 2
+    assert close_dot(a[:2000, :P].cpu().numpy(), X[:2000].cpu().numpy())
+    assert torch.equal(a[:, P:], dense)

@@ -53,7 +53,7 @@ def test_matches_the_oracle(dev, B, S, n_neg, fh):
         seq[1] = rng.integers(1, 300, size=S)     # a full sequence
     logits, si = run(dev, P, T, seq, pos, neg)
     exp, _ = ref.sasrec_forward(seq, pos, neg, T[0], T[1], T[2], [P], 1)
-    assert close(logits, exp, 2e-5)
+    assert close(logits, exp, 1e-5)
     assert np.all(logits[0] == 0.0) and np.all(si[0] == 0.0)
 
 
@@ -68,7 +68,7 @@ def test_pads_in_the_middle_and_masked_last_position(dev):
     seq[6:, -1] = 7
     logits, si = run(dev, P, T, seq, pos, neg)
     exp, _ = ref.sasrec_forward(seq, pos, neg, T[0], T[1], T[2], [P], 1)
-    assert close(logits, exp, 2e-5)
+    assert close(logits, exp, 1e-5)
     assert np.all(logits[:6] == 0.0)
 
 
@@ -86,7 +86,7 @@ def test_out_of_range_ids_are_zero_rows_and_flagged(dev):
     assert int(flag.item()) == 1
     # the oracle's embedding_lookup answers out-of-range ids with zero rows too (TF-GPU GatherV2 semantics)
     exp, _ = ref.sasrec_forward(seq2, pos, neg2, T[0], T[1], T[2], [P], 1)
-    assert close(logits, exp, 2e-5)
+    assert close(logits, exp, 1e-5)
     assert logits[2, 2] == 0.0
 
 
@@ -107,7 +107,7 @@ def test_strided_ids_and_pad_id_minus_one(dev):
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     logits, _ = ops.sasrec_last_row(weights_of(P, dev), 1e-6, 1e-6, tt[0], wide[:, 3:3 + S], -1, orig[:, -1], orig.stride(0),
                                     tt[1], tp, tt[2], tn, oob_flag=flag)
-    assert close(logits.cpu().numpy(), exp, 2e-5)
+    assert close(logits.cpu().numpy(), exp, 1e-5)
     assert int(flag.item()) == 0                   # pad_id rows are not out-of-range rows
 
 
@@ -130,7 +130,7 @@ def test_model_paths_agree(dev, monkeypatch):
     emb_a = m.embed.cpu().numpy()
     monkeypatch.setenv("REC_SASREC_IMPL", "layers")
     b = m([seq, pos, neg]).cpu().numpy()
-    assert close(a, b, 2e-5) and close(emb_a, m.embed.cpu().numpy(), 2e-5)
+    assert close(a, b, 1e-5) and close(emb_a, m.embed.cpu().numpy(), 1e-5)
 
 
 def test_rejects_unsupported_shapes(dev):

@@ -9,7 +9,28 @@
                any summation order; a regression to bf16 / tf32 products (1e-3 of the scale) fails by three orders.
 `close_dot`    close_scaled for all row-pair dots of X (B, n, D) with scale = sum_k |x_ik x_jk|.
 `fmaf_chain_dot` the exact arithmetic of the LDS-ring / fp32-MFMA kernel, emulated (bit-level pin)."""
+import os
+
 import numpy as np
+
+# Every tolerance check records how much of its bound it used: test id -> {"kind", "tol", "used" = max err / bound over
+# the test's checks, "max_abs_err"}.  tests/conftest.py writes the table to gpurun_out/parity_margins.json at the end of a
+# GPU session; the committed copy is profiles/rNN_parity_margins.json — a regression from 3e-7 to 9e-6 shows there while
+# the test still passes.
+MARGINS = {}
+
+
+def _record(kind, tol, err, bound):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    if not test or err.size == 0:
+        return
+    with np.errstate(divide="ignore", invalid="ignore"):
+        used = float(np.nanmax(np.where(bound > 0, err / bound, np.where(err > 0, np.inf, 0.0))))
+    m = MARGINS.setdefault(test, {"kind": kind, "tol": tol, "used": 0.0, "max_abs_err": 0.0, "checks": 0})
+    m["used"] = max(m["used"], used)
+    m["max_abs_err"] = max(m["max_abs_err"], float(np.nanmax(err)))
+    m["tol"] = max(m["tol"], tol)
+    m["checks"] += 1
 
 
 def close(a, b, tol=1e-5):
@@ -19,6 +40,7 @@ def close(a, b, tol=1e-5):
     assert a.shape == b.shape, (a.shape, b.shape)
     err = np.abs(a - b)
     bound = tol * np.maximum(1.0, np.abs(b))
+    _record("model |a-b| <= tol max(1,|b|)", tol, err, np.broadcast_to(bound, err.shape))
     ok = np.all(err <= bound)
     if not ok:
         i = np.unravel_index(np.argmax(err - bound), err.shape)
@@ -32,6 +54,7 @@ def close_scaled(a, b, scale, tol=1e-5, floor=1e-3, ulps=2.5e-7):
     assert a.shape == b.shape, (a.shape, b.shape)
     err = np.abs(a - b)
     bound = tol * np.maximum(np.abs(b), floor) + ulps * np.asarray(scale, np.float64)
+    _record("kernel |a-b| <= tol max(|b|,floor) + ulps scale", tol, err, np.broadcast_to(bound, err.shape))
     ok = bool(np.all(err <= bound))
     if not ok:
         w = np.unravel_index(np.argmax(err / bound), err.shape)
@@ -74,3 +97,11 @@ def fmaf_chain_dot(X, order):
 
 # column order of the ring kernel's chain: MFMA (j, i) covers k-slots q = 0..3 = columns 16j + 4q + i
 RING_ORDER = [16 * j + 4 * q + i for j in range(8) for i in range(4) for q in range(4)]
+
+
+def ring_order(D):
+    """the same chain for the generalised ring kernel (pairwise_dot_ring_gen.hip): a unit is 64 columns (D = 64) or 128
+    columns (D = 128, and each half of D = 256), walked as above"""
+    unit = 64 if D == 64 else 128
+    return [u * unit + 16 * j + 4 * q + i for u in range(D // unit) for j in range(unit // 16) for i in range(4)
+            for q in range(4)]
