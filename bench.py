@@ -101,6 +101,9 @@ def parse():
     ap.add_argument("--placed-candidates", type=int, default=6,
                     help="side measurement `placed`: the headline step on the best of this many arenas (0 = skip)")
     ap.add_argument("--din-width", type=int, default=64, help="--workload din: table width (3 tables; BASELINE configs[3] = 64)")
+    ap.add_argument("--transport", choices=["cabi", "torch"], default=None,
+                    help="rowshard: 'cabi' = the library's RCCL communicator, 'torch' = torch.distributed collectives "
+                         "(default: cabi under the nccl backend, with a visible fallback to torch)")
     ap.add_argument("--cache-rows", type=int, default=0, help="rowshard: hot-row replicas per rank (0 = off)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-spawned N > 1 run: watchdog of the rank processes (s)")
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
@@ -169,7 +172,7 @@ def wl_dlrm(torch, dev, a, rank, world, fused=True):
         from recamd.dist import ShardedTables
         # shard + replica cache + receive slots in ONE allocation (the row space the consumer kernels address)
         sharded = ShardedTables.empty(F, [V] * F, D, rank, world, dev, max_ids=B * F, cache_rows=a.cache_rows,
-                                      cache_refresh_every=16 if a.cache_rows else 0)
+                                      cache_refresh_every=16 if a.cache_rows else 0, transport=a.transport)
         arena = sharded.arena
         arena.uniform_(-0.05, 0.05, generator=gen)
         group = None
@@ -295,7 +298,9 @@ def wl_sasrec(torch, dev, a, rank, world):
           {'feat': 'neg_item', 'feat_num': V, 'feat_len': n, 'embed_dim': d}]
     kw = {}
     if a.placement == "rowshard":
-        kw = {"sharded": (rank, world)}
+        from recamd.dist import ShardedTables
+        kw = {"sharded": (rank, world),
+              "shard_factory": lambda tabs, vocabs, r, w: ShardedTables(tabs, vocabs, r, w, transport=a.transport)}
     m = SASRec(uf, [], blocks=1, num_heads=1, att_hidden_unit=d, ffn_hidden_unit=128, seq_len=S, neg_len=n, **kw)
     gen = torch.Generator(device=dev).manual_seed(5 + rank)
     batches, real = [], 0
@@ -399,6 +404,8 @@ def launch_ranks(a):
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
             rc = max(abs(c) for c in codes)
+            if rc:
+                why = "rank exit codes " + str(codes)
             break
         bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
         if bad or time.time() > deadline:
@@ -485,7 +492,7 @@ def main():
 
     def build(wl, placement):
         a.placement = placement
-        if placement == "rowshard" and world > 1 and "REC_SHARD_TRANSPORT" not in os.environ:
+        if placement == "rowshard" and world > 1 and a.transport is None:
             # the library's own RCCL communicator first; if it cannot be created here, the same exchange over
             # torch.distributed's collectives (every rank takes the same branch: the failure modes are per-node) —
             # and the line SAYS so (config.exchange.transport / .fallback)
@@ -494,7 +501,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 transport_note["fallback"] = f"C-ABI RCCL transport failed ({type(e).__name__}: {str(e)[:160]})"
                 print(f"[bench] rank {rank}: {transport_note['fallback']}; using torch.distributed", file=sys.stderr, flush=True)
-                os.environ["REC_SHARD_TRANSPORT"] = "torch"
+                a.transport = "torch"
         return build_(wl)
 
     def build_(wl):

@@ -65,6 +65,11 @@ typedef struct rec_table_desc {
 int rec_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
 int rec_last_error(char* buf, int n);
+/* Kernel selection is by shape only and the library reads NO environment variable.  Tests and A/B scripts may force a
+ * kernel variant that a shape would not select: key / value pairs listed in csrc/common.h ("dense" "b"|"f"|"s"|"t",
+ * "mha" "f"|"v", "din" "l"|"s", "pairdot" "v", "topk" "f", "cross" "l", ...); value NULL or "" clears the key.
+ * Process-global, not thread-safe, never set by the product. */
+int rec_debug_force(const char* key, const char* value);
 
 /* ---- a1 / K1: per-field Embedding gather + concat -------------------------------------------
  * Replaces  tf.concat([Embedding_f(sparse_inputs[:, f]) for f], axis=-1)

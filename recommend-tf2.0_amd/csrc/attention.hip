@@ -765,9 +765,9 @@ extern "C" int rec_mha_ctr_f32(const float* xq, const float* xk, const float* xv
   if (B == 0) return REC_OK;
   REC_CHECK_ARG(xq && xk && xv && Wq && Wk && Wv && out, REC_EINVAL, "%s: NULL pointer", who);
   {
-    // default: bf16x3 kernel (attention_ctr.hip) for the AutoInt shapes; REC_MHA_IMPL = "f32" keeps the fp32-MFMA
-    // kernel, "valu" the LDS/VALU kernel (A/B only)
-    const char* e = getenv("REC_MHA_IMPL");
+    // default: bf16x3 kernel (attention_ctr.hip) for the AutoInt shapes; rec_debug_force("mha", "f") keeps the fp32-MFMA
+    // kernel, "v" the LDS/VALU kernel (tests / A/B only)
+    const char* e = forced("mha");
     if (!(e && (e[0] == 'v' || e[0] == 'f')) && mha_ctr_b3_dispatch(xq, xk, xv, B, N, din, Wq, Wk, Wv, W0, H, S, act, out,
                                                                      reinterpret_cast<hipStream_t>(stream))) {
       REC_CHECK_LAUNCH(who);
@@ -848,18 +848,13 @@ extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
   // ids of a sample staged in LDS + pipelined row loads (din_gather_pool_lds_kernel) while the 4 waves' id lists fit
-  // 48 KiB; longer histories keep the streaming kernel.  REC_DIN_IMPL=stream (read once): A/B.
-  static const bool lds_ok = [] {
-    const char* e = getenv("REC_DIN_IMPL");
-    return !(e && e[0] == 's');
-  }();
+  // 48 KiB; longer histories keep the streaming kernel.  rec_debug_force("din", "s" | "l"): tests / A/B.
+  const char* din_forced = forced("din");
+  const bool lds_ok = !(din_forced && din_forced[0] == 's');
   const size_t lds = (size_t)4 * T * (n_tab + 1) * sizeof(int32_t);
   // 64-wide tables (16 lanes x 16 B per row): one lane group per history slot (din_gather_pool_grp_kernel);
   // REC_DIN_IMPL=lds keeps the wave-per-slot kernel for A/B
-  static const bool grp_ok = [] {
-    const char* e = getenv("REC_DIN_IMPL");
-    return !(e && (e[0] == 's' || e[0] == 'l'));
-  }();
+  const bool grp_ok = !(din_forced && (din_forced[0] == 's' || din_forced[0] == 'l'));
   // rows of 16 / 32 / 64 / 128 floats (4 / 8 / 16 / 32 lanes x 16 B): one lane group per history slot
   // (din_gather_pool_grp_kernel; 64 is the BASELINE configs[3] width).  Register budget: NTAB x LPR <= 64 (d <= 256)
   if (grp_ok && (Dt == 64 || Dt == 32 || Dt == 16 || Dt == 128) && n_tab <= 4 && n_tab * Dt <= 256 && lds <= 48 * 1024) {
@@ -931,8 +926,8 @@ extern "C" int rec_mha_rowmask_strided_f32(const float* q, int64_t q_stride, con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     // default for Sq > 8, dk in {32, 64}: bf16x3 matrix-core kernel streaming K/V tiles (attention_b3.hip; no
-    // sequence-length limit).  REC_MHA_IMPL = "f32" keeps the fp32-MFMA kernel, "valu" the round-1 VALU kernel.
-    const char* e = getenv("REC_MHA_IMPL");
+    // sequence-length limit).  rec_debug_force("mha", "f") keeps the fp32-MFMA kernel, "v" the round-1 VALU kernel.
+    const char* e = forced("mha");
     if (!(e && (e[0] == 'v' || e[0] == 'f')) && Sq > 8 &&
         mha_rowmask_b3_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, q_stride, k_stride, v_stride, st)) {
       REC_CHECK_LAUNCH(who);
@@ -948,7 +943,7 @@ extern "C" int rec_mha_rowmask_strided_f32(const float* q, int64_t q_stride, con
   const size_t lds = (size_t)2 * Sk * dk * sizeof(float);
   REC_CHECK_ARG(lds <= 160 * 1024, REC_ESHAPE, "%s: Sk=%d dk=%d needs %zu B of LDS", who, Sk, dk, lds);
   {
-    const char* e = getenv("REC_MHA_IMPL");  // "valu" forces the round-1 VALU kernel (A/B only)
+    const char* e = forced("mha");  // "v" forces the round-1 VALU kernel (tests / A/B only)
     if (!(e && e[0] == 'v') && mha_rowmask_mfma_dispatch(q, k, v, mask, B, Sq, Sk, dk, H, out, st)) {
       REC_CHECK_LAUNCH(who);
       return REC_OK;

@@ -416,8 +416,8 @@ bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const Ctr
   }
   int64_t blocks = (B + 3) / 4;
   // workgroups per CU that are RESIDENT at once (the kernels use 196 VGPRs: two waves per SIMD = two workgroups of four
-  // waves): with more, the surplus workgroups run as a second round and stage the weights again.  REC_AUTOINT_WG_PER_CU: A/B
-  static const int wg_per_cu = [] { const char* e = getenv("REC_AUTOINT_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v; }();
+  // waves): with more, the surplus workgroups run as a second round and stage the weights again.  rec_debug_force("autoint_wg", n): A/B
+  const int wg_per_cu = forced("autoint_wg") ? atoi(forced("autoint_wg")) : 0;
   const int wg_res = wg_per_cu > 0 ? wg_per_cu : ((NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2);   // as the kernel's launch bounds
   if (blocks > (int64_t)cus * wg_res) blocks = (int64_t)cus * wg_res;
   const dim3 grid((unsigned)blocks), block(256);
@@ -461,11 +461,8 @@ bool mha_ctr_b3_dispatch(const float* xq, const float* xk, const float* xv, int6
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
   const int NT = (N + 15) / 16;
   // default for H <= 2: the register-resident fp32-MFMA kernel (a stack of one layer);
-  // REC_MHA_CTR_IMPL=b3 (read once) keeps the bf16x3 kernel of this file for A/B, and it serves H > 2
-  static const bool use_b3 = [] {
-    const char* e = getenv("REC_MHA_CTR_IMPL");
-    return e && e[0] == 'b';
-  }();
+  // rec_debug_force("mha_ctr", "b") keeps the bf16x3 kernel of this file for tests / A/B, and it serves H > 2
+  const bool use_b3 = forced("mha_ctr") && forced("mha_ctr")[0] == 'b';
   if (!use_b3) {
     CtrStackArgs wa{};
     wa.Wq[0] = Wq, wa.Wk[0] = Wk, wa.Wv[0] = Wv, wa.W0[0] = W0;

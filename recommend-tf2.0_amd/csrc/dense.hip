@@ -299,10 +299,10 @@ void dense_prepare_launch(const float* W, int K, int N, void* Wp, hipStream_t st
 bool dense_b3_rows_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
                             int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st);
 
-// REC_DENSE_IMPL: 's' = keep the fp32-MFMA skinny kernels (instead of the bf16x3 row-streaming form), 't' = fp32-MFMA tiled kernel for everything, 'f' = fp32 MFMA instead of the bf16x3 kernel,
+// rec_debug_force("dense", ...): 's' = keep the fp32-MFMA skinny kernels (instead of the bf16x3 row-streaming form), 't' = fp32-MFMA tiled kernel for everything, 'f' = fp32 MFMA instead of the bf16x3 kernel,
 // 'b' = bf16x3 kernel wherever it is applicable (A/B measurements)
 static char dense_impl() {
-  const char* e = getenv("REC_DENSE_IMPL");
+  const char* e = forced("dense");
   return e ? e[0] : 0;
 }
 

@@ -523,8 +523,8 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
 #define REC_B3_GO(XM_, BP_)                                                                                      \
   hipLaunchKernelGGL((dense_bf16x3_kernel<XM_, BP_>), grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, \
                      N, out, out_stride, out_vec, wp, Np, xcd_map)
-  // aligned x rows + prepared W + K a multiple of 32: the hand-counted pipeline (REC_DENSE_PIPE=0 reads once: A/B)
-  static const bool pipe_ok = [] { const char* e = getenv("REC_DENSE_PIPE"); return !(e && e[0] == '0'); }();
+  // aligned x rows + prepared W + K a multiple of 32: the hand-counted pipeline (rec_debug_force("dense_pipe", "0"): A/B)
+  const bool pipe_ok = !(forced("dense_pipe") && forced("dense_pipe")[0] == '0');
   if (pipe_ok && wp && x_vec == 1 && K % 32 == 0 && K >= 32) {
     hipLaunchKernelGGL(dense_bf16x3_pipe_kernel, grid, dim3(256), 0, st, x, x_stride, bias, alpha, act, M, K, N, out,
                        out_stride, out_vec, wp, Np, xcd_map);

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void pairdot_generic_gather_kernel(TableSet ts
 
 int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const char* who);
 // D = 128 fused form on the LDS-DMA ring + fp32 matrix cores (pairwise_dot_ring.hip): the default for the shapes it
-// covers (int32 ids, 16-B aligned padded output rows).  REC_PAIRDOT_IMPL=valu (read once) keeps the register-tiled
+// covers (int32 ids, 16-B aligned padded output rows).  rec_debug_force("pairdot", "v") keeps the register-tiled
 // kernel of this file for A/B measurements.  Earlier variants that lost (LDS-transposed fp32 MFMA, software-pipelined
 // VALU, bf16x3 Gram) live under tools/exp/pairdot_variants/ and are not part of the library.
 bool pairdot128_ring_dispatch(const TableSet& ts, int F, bool has_dense, int ids_f32, const void* ids,
@@ -344,12 +344,9 @@ bool pairdot128_ring_dispatch(const TableSet& ts, int F, bool has_dense, int ids
 bool pairdot_ring_gen_dispatch(const TableSet& ts, int F, int D, bool has_dense, int ids_f32, const void* ids,
                                int64_t ids_stride, const float* dense, int64_t dense_stride, int64_t B, float* out,
                                int64_t out_stride, int append_dense, int* oob, hipStream_t st);
-static bool use_ring() {
-  static const bool on = [] {
-    const char* e = getenv("REC_PAIRDOT_IMPL");
-    return !(e && e[0] == 'v');
-  }();
-  return on;
+static bool use_ring() {  // rec_debug_force("pairdot", "v") keeps the register-tiled kernel (tests / A/B only)
+  const char* e = forced("pairdot");
+  return !(e && e[0] == 'v');
 }
 
 template <int LPR, int N, bool GATHER, bool HAS_DENSE, int IDS_F32>

@@ -343,6 +343,10 @@ PYBIND11_MODULE(_C, m) {
           "rec_unpermute_rows_f32");
   });
   // ---- communicator + sharded-lookup plan (opaque handles cross as integers) ----------------------------
+  m.def("debug_force", [](const std::string& key, py::object value) {   // tests / A-B only (rec_debug_force)
+    if (value.is_none()) check(rec_debug_force(key.c_str(), nullptr), "rec_debug_force");
+    else check(rec_debug_force(key.c_str(), value.cast<std::string>().c_str()), "rec_debug_force");
+  });
   m.def("comm_unique_id", []() {
     char id[128];
     check(rec_comm_unique_id(id), "rec_comm_unique_id");

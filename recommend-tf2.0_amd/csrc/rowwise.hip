@@ -943,11 +943,11 @@ extern "C" int rec_cross_f32(const float* x, int64_t x_stride, int32_t dim, cons
                    x_stride % 4 == 0 && out_stride % 4 == 0 && dim <= 4096;
   if (vec) {
     const int vpl = (dim / 4 + 63) / 64;
-    const bool literal = getenv("REC_CROSS_IMPL") && getenv("REC_CROSS_IMPL")[0] == 'l';  // A/B only
+    const bool literal = forced("cross") && forced("cross")[0] == 'l';  // rec_debug_force: tests / A/B only
     if (!literal && L >= 1 && L <= kCrossMaxL) {
       int64_t blocks = (B + 3) / 4;
       int bpc = 4;  // 102 VGPRs -> 4 waves/SIMD = 4 workgroups per CU resident (measured 4/6/8: 0.466/0.523/0.513 ms)
-      if (const char* e = getenv("REC_CROSS_BPC")) bpc = atoi(e) > 0 ? atoi(e) : bpc;
+      if (const char* e = forced("cross_bpc")) bpc = atoi(e) > 0 ? atoi(e) : bpc;
       if (blocks > 256 * bpc) blocks = 256 * bpc;  // persistent: the prologue runs once per workgroup
       const size_t lds = (size_t)dim * sizeof(float);
 #define REC_CROSS_C(V)                                                                                \

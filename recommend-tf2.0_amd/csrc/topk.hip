@@ -496,7 +496,7 @@ extern "C" int rec_topk_ip_ws_f32(const float* queries, int64_t q_stride, int64_
   REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "%s: too many queries", who);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
-    const char* e = getenv("REC_TOPK_IMPL");  // "f32": fp32-MFMA kernel (A/B only)
+    const char* e = forced("topk");  // "f": fp32-MFMA kernel (rec_debug_force: tests / A/B only)
     if (!(e && e[0] == 'f') && d <= 64) {  // d > 64: the bf16x3 form would spill (96 query + 64 staging VGPRs)
       const int vec_ok = (aligned16(queries) && aligned16(items) && q_stride % 4 == 0 && items_stride % 4 == 0) ? 1 : 0;
       const int nsplit = workspace ? topk_nsplit(Q, N, k) : 1;

@@ -20,8 +20,9 @@ from recamd.nn import Model, to_device_f32, to_device_ids
 class AutoInt(Model):
     def __init__(self, feature_columns, att_hidden_units, att_activation='relu',
                  dnn_dropout=0., embed_reg=1e-4, mode='intended', head_num=1, att_layer_num=1,
-                 use_res=False, embed_dense=True):
+                 use_res=False, embed_dense=True, fused=True):
         super().__init__()
+        self.fused = fused          # False: separate launches even where the one-launch kernel applies
         if mode not in ('intended', 'as_written'):
             raise ValueError("mode must be 'intended' or 'as_written'")
         self.mode = mode
@@ -61,10 +62,9 @@ class AutoInt(Model):
 
     def _fused_forward(self, dense_inputs, sparse_inputs, F, D):
         """the whole call — lookup, dense-field embedding, interacting layers, Dense(1), sigmoid — in ONE launch
-        (rec_autoint_forward_f32) when the configuration is covered; None otherwise.  REC_AUTOINT_IMPL=layers keeps
-        the separate launches."""
-        import os
-        if os.environ.get('REC_AUTOINT_IMPL') == 'layers' or sparse_inputs.dtype != torch.int32:
+        (rec_autoint_forward_f32) when the configuration is covered; None otherwise.  `self.fused = False` keeps the
+        separate launches."""
+        if not self.fused or sparse_inputs.dtype != torch.int32:
             return None
         layers = self.attention_layers
         hs = layers[0]._head_num * layers[0]._head_size

@@ -23,7 +23,7 @@ class SASRec(Model):
                  user_dense_feature_columns=(), item_dense_feature_columns=(),
                  blocks=1, num_heads=1, att_hidden_unit=128, ffn_hidden_unit=128,
                  dnn_dropout=0., layer_norm_eps=1e-6, seq_len=10, neg_len=100, embed_reg=1e-6,
-                 last_row_only=True, sharded=None, shard_factory=None):
+                 last_row_only=True, sharded=None, shard_factory=None, fused=True):
         super().__init__()
         from recamd.dist import ShardedTables, local_rows_of
         if isinstance(sharded, ShardedTables):
@@ -71,6 +71,7 @@ class SASRec(Model):
         self.encoder_layer = [self.track('encoder_%d' % i, TransformerEncoder(
             self.d_model, num_heads, ffn_hidden_unit, dnn_dropout, layer_norm_eps)) for i in range(blocks)]
         self.last_row_only = last_row_only
+        self.fused = fused          # False: the layer-by-layer path even where the one-launch kernel applies
         self._logits = None
         self.embed = None
 
@@ -148,10 +149,9 @@ class SASRec(Model):
 
     def _fused_block(self, S, seq_inputs, pos_inputs, neg_inputs):
         """The 13 weight tensors of the single encoder block when the one-launch kernel serves this configuration
-        (one block, one head, last row only, d_model 64, ffn 64/128, int32 ids), else None.  REC_SASREC_IMPL=layers
-        keeps the layer-by-layer path."""
-        import os
-        if len(self.encoder_layer) != 1 or not self.last_row_only or os.environ.get('REC_SASREC_IMPL') == 'layers':
+        (one block, one head, last row only, d_model 64, ffn 64/128, int32 ids), else None.  `self.fused = False` keeps
+        the layer-by-layer path."""
+        if len(self.encoder_layer) != 1 or not self.last_row_only or not self.fused:
             return None
         enc = self.encoder_layer[0]
         if enc.mha.num_heads != 1 or any(t.dtype != torch.int32 for t in (seq_inputs, pos_inputs, neg_inputs)):

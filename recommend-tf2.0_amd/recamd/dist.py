@@ -191,9 +191,6 @@ class ShardedTables:
         self._shift = (torch.arange(self.F, dtype=torch.int32, device=dev) * self.vpad)[None, :]
         self._vocab_t = torch.tensor(self.vocabs, dtype=torch.int32, device=dev)[None, :]
         if transport is None:
-            import os
-            transport = os.environ.get("REC_SHARD_TRANSPORT") or None      # 'cabi' | 'torch': overrides the default below
-        if transport is None:
             is_nccl = world > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
             transport = "cabi" if (is_nccl and dev.type == "cuda") else "torch"
         if transport not in self._transports():
@@ -545,17 +542,23 @@ class ShardedTables:
             self._local_group = ops.TableGroup([self.tables[f][:self.vocabs[f]] for f in range(self.F)])
         return self._local_group
 
-    def lookup_rows(self, vids: torch.Tensor):
+    def lookup_rows(self, vids: torch.Tensor, keep_plan: bool = False):
         """Generic form: flat virtual ids (virtual_ids(); -1 = skip) -> (rows, uidx): lookup i reads rows[uidx[i]]
         (uidx -1 = zero row).  The consumer kernels take `rows` (the row space) as their table and `uidx` as their ids;
-        the returned index stays valid until `slots` further lookups have been planned."""
+        the returned index stays valid until `slots` further lookups have been planned.  keep_plan=True returns
+        (rows, uidx, plan) for backward(plan, dy (n_lookups, D), grad_arena); the plan holds its receive slot until then
+        (world == 1: plan is None, the gradient of lookup i belongs to row uidx[i] of the arena)."""
         vids = vids.reshape(-1).contiguous()
         if self.world == 1:
             # every row is local: the arena IS the row space, local row = virtual row (Vpad = padded vocabulary)
-            return self.arena, vids
-        p = self._plan_vids(vids, None, 0)
+            return (self.arena, vids, None) if keep_plan else (self.arena, vids)
+        p = self._plan_vids(vids, None, 0, use_cache=not keep_plan)
         self._ready(p)
         uidx = p.uidx if self.transport != "cabi" else p.uidx.clone()    # the slot's workspace is reused; the index is small
+        if keep_plan:
+            p.uidx = uidx
+            p.recv_local = p.recv_local.clone()     # the shared serve buffer is rewritten by the next exchange
+            return self.space, uidx, p
         self._release(p)
         return self.space, uidx
 
@@ -642,6 +645,8 @@ class ShardedTables:
         all ranks' lookups.  `plan` is the one lookup(..., keep_plan=True) returned."""
         D = self.D
         dyr = dy.reshape(-1, D)
+        if plan is None:                       # world == 1 (lookup_rows): every lookup is a row of the arena
+            raise ValueError("backward: world == 1 has no plan; scatter-add dy by the returned index into the gradient arena")
         uidx = plan.uidx
         neg = torch.full_like(uidx, -1)
         # lookups answered from this rank's shard: straight into the gradient arena

@@ -355,12 +355,30 @@ class TrainState:
     def __init__(self, model: nn.Layer):
         self.model = model
         self._grads: Dict[str, torch.Tensor] = {}
+        self._sharded: Dict[int, torch.Tensor] = {}
+        self.owner_summed = set()      # row-sharded tables: gradients arrive summed at the owner, never all-reduced
 
     def grad(self, name: str) -> torch.Tensor:
         w = named_weights(self.model)[name]
         if name not in self._grads:
             self._grads[name] = torch.zeros_like(w)
         return self._grads[name]
+
+    def sharded_grad(self, st, names: Sequence[str]) -> torch.Tensor:
+        """Gradient arena of row-sharded tables (recamd.dist.ShardedTables `st`; names[f] = weight name of table f): one
+        (F * rows_local, D) buffer in the arena's layout — what ShardedTables.backward scatter-adds into — whose
+        per-table row ranges are the tables' gradient buffers.  These gradients are already summed over the ranks by the
+        reverse all-to-all (every rank owns its rows): `owner_summed` keeps them out of the data-parallel all-reduce."""
+        key = id(st)
+        if key not in self._sharded:
+            ga = torch.zeros_like(st.arena)
+            self._sharded[key] = ga
+            weights = named_weights(self.model)
+            for f, n in enumerate(names):
+                rows = weights[n].shape[0]
+                self._grads[n] = ga[f * st.rows_local: f * st.rows_local + rows]
+                self.owner_summed.add(n)
+        return self._sharded[key]
 
 
 class Adam:
@@ -570,7 +588,8 @@ def train_step(model, opt: Adam, state: TrainState, inputs, y_true, allreduce: O
             grads[k] = grads[k].contiguous()
             allreduce(grads[k])
         for k in sorted(state._grads):
-            allreduce(state._grads[k])
+            if k not in state.owner_summed:
+                allreduce(state._grads[k])
     sparse_ids = None
     if opt.sparse:
         if type(model).__name__ not in ("DLRM", "DeepFM", "DCN"):

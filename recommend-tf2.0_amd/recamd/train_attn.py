@@ -298,11 +298,44 @@ def _rows_fwd(tape: Tape, state: TrainState, table: torch.Tensor, name: str, ids
     return gather_concat_fwd(tape, state, ops.TableGroup([table]), [name], ids.reshape(-1, 1).contiguous())
 
 
+def rows_slice_fwd(tape: Tape, x: Var, lo: int, hi: int) -> Var:
+    """rows lo..hi-1 of a (n, d) activation (a view); the gradient is added into the same rows of x.g"""
+    y = Var(x.v[lo:hi])
+
+    def bwd():
+        if y.g is None:
+            return
+        if x.g is None:
+            x.g = torch.zeros_like(x.v)
+        x.g[lo:hi] += y.g
+    tape.ops.append(bwd)
+    return y
+
+
+def _sharded_rows_fwd(tape: Tape, state: TrainState, st, names, vids: torch.Tensor) -> Var:
+    """All lookups of a model through ONE sharded exchange (recamd.dist.ShardedTables): (n_lookups, d) rows, zero for
+    vids = -1.  Backward: the gradient of every lookup travels to the owner of its row (local rows directly, remote
+    ones by the reverse all-to-all) into the sharded gradient arena (state.sharded_grad)."""
+    space, uidx, plan = st.lookup_rows(vids, keep_plan=True)
+    E = Var(ops.gather_concat(ops.TableGroup([space]), uidx.reshape(-1, 1).contiguous()))
+
+    def bwd():
+        ga = state.sharded_grad(st, names)
+        g = E.g if E.g is not None else torch.zeros_like(E.v)
+        if plan is None:                       # one rank: the arena is the row space, uidx the arena row
+            ops.embedding_grad(ops.TableGroup([ga]), uidx.reshape(-1, 1).contiguous(), g)
+        else:
+            st.backward(plan, g, ga)
+    tape.ops.append(bwd)
+    return E
+
+
 def sasrec_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, grad_scale: float = 1.0):
     """src/match/sasrec/model.py:60-97, training mode: every block encodes all positions (the gradients of the K / V
-    projections need them); the loss is the model's add_loss (:93-95).  Returns (logits, loss)."""
-    if m._sharded is not None:
-        raise NotImplementedError("training: SASRec with row-sharded tables goes through ShardedTables.backward (recamd.dist)")
+    projections need them); the loss is the model's add_loss (:93-95).  Returns (logits, loss).
+    Row-sharded tables (SASRec(sharded=...), BASELINE configs[4]): the seq / pos / neg lookups of :75-79 travel in one
+    exchange and their gradients return to the owners through ShardedTables.backward; every rank scales its loss by
+    grad_scale = 1 / world, the dense parameters merge by all-reduce (train_step), the tables never do."""
     seq, pos, neg = [nn.to_device_ids(t, m.device) for t in inputs]
     seq, pos, neg = [t if t.dtype == torch.int32 else t.to(torch.int32) for t in (seq, pos, neg)]
     B, S = seq.shape
@@ -311,8 +344,16 @@ def sasrec_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, 
     tb = m.user_embed_layers
     names = {k: f"user_embed_{k}/embeddings" for k in ("seq_item", "pos_item", "neg_item")}
     mask = (seq != 0).to(torch.float32).contiguous()                                                    # :72
-    seq_m = torch.where(seq == 0, torch.full_like(seq, -1), seq)            # `seq_embed * mask` (:81-82): pad rows are zero
-    x = _rows_fwd(tape, state, tb['embed_seq_item'].table, names["seq_item"], seq_m)                  # (B*S, d), :75
+    st = m._sharded
+    if st is not None:
+        vids = torch.cat([st.virtual_ids(0, seq, pad_id=0).reshape(-1), st.virtual_ids(1, pos).reshape(-1),
+                          st.virtual_ids(2, neg).reshape(-1)])
+        E = _sharded_rows_fwd(tape, state, st, [names["seq_item"], names["pos_item"], names["neg_item"]], vids)
+        x = rows_slice_fwd(tape, E, 0, B * S)                                                           # (B*S, d), :75, :81-82
+        cand = rows_slice_fwd(tape, E, B * S, B * S + B * (1 + n_neg))    # pos rows (B), then neg rows (B * n_neg)
+    else:
+        seq_m = torch.where(seq == 0, torch.full_like(seq, -1), seq)        # `seq_embed * mask` (:81-82): pad rows are zero
+        x = _rows_fwd(tape, state, tb['embed_seq_item'].table, names["seq_item"], seq_m)              # (B*S, d), :75
     rate = float(getattr(m.dropout, "rate", 0.0) or 0.0)
     mflat = mask.reshape(-1)
     for bi, enc in enumerate(m.encoder_layer):                                                          # :84-86
@@ -338,9 +379,16 @@ def sasrec_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, 
         xs.acc(g.view(B * S, d))
     tape.ops.append(bwd_last)
     logits = torch.empty((B, 1 + n_neg), dtype=torch.float32, device=m.device)
-    pos_t, neg_t = tb['embed_pos_item'].table, tb['embed_neg_item'].table
-    ops.gather_dot_scores(seq_info.v, pos_t, pos.contiguous(), out=logits[:, :1])                        # :77, :90
-    ops.gather_dot_scores(seq_info.v, neg_t, neg.contiguous(), out=logits[:, 1:])                        # :79, :91
+    if st is not None:
+        # the candidate rows arrived with the exchange: "table" = those rows, "ids" = their positions
+        pos_t = neg_t = cand.v
+        pos_i = torch.arange(B, dtype=torch.int32, device=m.device).view(B, 1)
+        neg_i = (B + torch.arange(B * n_neg, dtype=torch.int32, device=m.device)).view(B, n_neg)
+    else:
+        pos_t, neg_t = tb['embed_pos_item'].table, tb['embed_neg_item'].table
+        pos_i, neg_i = pos.contiguous(), neg.contiguous()
+    ops.gather_dot_scores(seq_info.v, pos_t, pos_i, out=logits[:, :1])                                   # :77, :90
+    ops.gather_dot_scores(seq_info.v, neg_t, neg_i, out=logits[:, 1:])                                   # :79, :91
     loss = ops.pairwise_rank_loss(logits)                                                               # :93-95
 
     def bwd_loss():
@@ -348,11 +396,16 @@ def sasrec_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, 
         C.pairwise_rank_loss_grad_f32(logits.data_ptr(), logits.stride(0), B, n_neg, float(grad_scale), dl.data_ptr(),
                                       dl.stride(0), _s())
         dseq = torch.empty((B, d), dtype=torch.float32, device=m.device)
-        gp, gn = state.grad(names["pos_item"]), state.grad(names["neg_item"])
-        C.gather_dot_scores_grad_f32(seq_info.v.data_ptr(), pos_t.data_ptr(), gp.data_ptr(), pos_t.shape[0], d, pos.data_ptr(),
-                                     pos.stride(0), pos.shape[1], dl.data_ptr(), dl.stride(0), B, dseq.data_ptr(), 0, _s())
-        C.gather_dot_scores_grad_f32(seq_info.v.data_ptr(), neg_t.data_ptr(), gn.data_ptr(), neg_t.shape[0], d, neg.data_ptr(),
-                                     neg.stride(0), n_neg, dl[:, 1:].data_ptr(), dl.stride(0), B, dseq.data_ptr(), 1, _s())
+        if st is not None:
+            gp = gn = torch.zeros_like(cand.v)
+        else:
+            gp, gn = state.grad(names["pos_item"]), state.grad(names["neg_item"])
+        C.gather_dot_scores_grad_f32(seq_info.v.data_ptr(), pos_t.data_ptr(), gp.data_ptr(), pos_t.shape[0], d, pos_i.data_ptr(),
+                                     pos_i.stride(0), pos_i.shape[1], dl.data_ptr(), dl.stride(0), B, dseq.data_ptr(), 0, _s())
+        C.gather_dot_scores_grad_f32(seq_info.v.data_ptr(), neg_t.data_ptr(), gn.data_ptr(), neg_t.shape[0], d, neg_i.data_ptr(),
+                                     neg_i.stride(0), n_neg, dl[:, 1:].data_ptr(), dl.stride(0), B, dseq.data_ptr(), 1, _s())
+        if st is not None:
+            cand.acc(gp)
         seq_info.acc(dseq)
     tape.ops.append(bwd_loss)
     m._logits = logits

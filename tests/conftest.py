@@ -14,6 +14,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def force():
+    """force("dense", "b"): a kernel variant the shape would not select (rec_debug_force: the library reads no environment
+    variable); every forced key is cleared when the test ends"""
+    from recamd._lib import C
+    keys = []
+
+    def _force(key, value):
+        keys.append(key)
+        C.debug_force(key, value)
+    yield _force
+    for k in keys:
+        C.debug_force(k, None)
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

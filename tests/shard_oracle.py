@@ -152,3 +152,22 @@ class PeersShardedTables(ShardedTables):
                 p.rows_ready = torch.cuda.Event()
                 p.rows_ready.record()
         p.exchanged = True
+
+    def backward(self, plan, dy, grad_arena):
+        """the reverse all-to-all, in process: the gradient rows of the unique remote lookups are scatter-added straight
+        into the owners' gradient arenas (`peer_grad_arena`, set by the test for every rank before the first backward)"""
+        D = self.D
+        dyr = dy.reshape(-1, D)
+        uidx = plan.uidx
+        neg = torch.full_like(uidx, -1)
+        self._dev_scatter_add_rows(grad_arena, torch.where((uidx >= 0) & (uidx < self.arena_rows), uidx, neg), dyr)
+        if plan.n_unique:
+            d_rows = torch.zeros((plan.n_unique, D), dtype=torch.float32, device=dy.device)
+            self._dev_scatter_add_rows(d_rows, torch.where(uidx >= plan.recv_base, uidx - plan.recv_base, neg), dyr)
+            off = 0
+            for o, c in enumerate(plan.send_splits):
+                if c:
+                    self._dev_scatter_add_rows(self.peers[o].peer_grad_arena, plan.send_local[off:off + c].contiguous(),
+                                               d_rows[off:off + c])
+                off += c
+        self._release(plan)

@@ -55,9 +55,9 @@ def test_dense_rank3_and_strided_input(dev):
 
 @pytest.mark.parametrize("M,K,N,aligned", [(2048, 512, 256, True), (1500, 479, 130, False), (1024, 42, 200, False),
                                            (4096, 64, 128, True)])
-def test_dense_bf16x3_has_fp32_accuracy(dev, monkeypatch, M, K, N, aligned):
+def test_dense_bf16x3_has_fp32_accuracy(dev, force, M, K, N, aligned):
     """The large-layer kernel rebuilds fp32 products from three bf16 terms (csrc/dense_bf16x3.hip): its error against
-    the fp64 oracle must be at the level of the fp32-MFMA kernel's (REC_DENSE_IMPL=f), and the three x staging paths
+    the fp64 oracle must be at the level of the fp32-MFMA kernel's (forced: "dense" "f"), and the three x staging paths
     (aligned rows / unaligned rows via the transpose tile / short-K scalar loads) must agree with the oracle."""
     from recamd import ops
     rng = np.random.default_rng(K)
@@ -68,20 +68,20 @@ def test_dense_bf16x3_has_fp32_accuracy(dev, monkeypatch, M, K, N, aligned):
     tx = t(x)
     assert (tx.stride(0) % 4 == 0) == aligned
     exp = ref.dense(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64), "relu")
-    monkeypatch.setenv("REC_DENSE_IMPL", "b")
+    force("dense", "b")
     got_b = ops.dense(tx, t(W), t(b), "relu").cpu().numpy()
-    monkeypatch.setenv("REC_DENSE_IMPL", "f")
+    force("dense", "f")
     got_f = ops.dense(tx, t(W), t(b), "relu").cpu().numpy()
     err_b, err_f = np.abs(got_b - exp).max(), np.abs(got_f - exp).max()
     assert close_scaled(got_b, exp, np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(b))
     assert err_b <= 2.0 * err_f + 1e-7, (err_b, err_f)
 
 
-def test_dense_bf16x3_tiny_and_mixed_magnitudes(dev, monkeypatch):
+def test_dense_bf16x3_tiny_and_mixed_magnitudes(dev, force):
     """values spanning 2^-20 .. 2^10 in one row: the hi/mid/lo split is exact per element, so small terms
     next to large ones keep their fp32 contribution"""
     from recamd import ops
-    monkeypatch.setenv("REC_DENSE_IMPL", "b")
+    force("dense", "b")
     rng = np.random.default_rng(1)
     M, K, N = 1024, 128, 96
     x = (rng.normal(size=(M, K)) * np.exp2(rng.integers(-20, 11, size=(M, K)))).astype(np.float32)

@@ -301,3 +301,81 @@ def _cache_worker(rank, world, port, ret):
 def test_hot_row_cache_gloo():
     ret = _spawn(_cache_worker, 2)
     assert all(ret.get(r) and ret[r][0] for r in range(2)), ret
+
+
+def _sasrec_train_worker(rank, world, port, V, S, n_neg, B, ret):
+    """TRAINING of the row-sharded SASRec (BASELINE configs[4]) through the exchange: the seq / pos / neg lookups travel as
+    one sharded lookup kept for backward; the loss (src/match/sasrec/model.py:93-95, scaled by 1 / world on every rank)
+    is differentiated by the fp64 autograd oracle down to the looked-up rows; ShardedTables.backward returns those row
+    gradients to the owners.  Every rank's gradient arena must equal its rows of the oracle's gradient of the GLOBAL mean
+    loss on the unsharded tables; the dense parameters' gradients merge by the all-reduce."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_torch
+        from recamd.dist import shard_table
+        from tests.shard_oracle import OracleShardedTables
+        d = 16
+        rng = np.random.default_rng(3)                      # same tables and weights on every rank
+        T = [rng.normal(size=(V, d)) * 0.3 for _ in range(3)]
+        blk = dict(Wq=rng.normal(size=(d, d)) * 0.2, bq=rng.normal(size=d) * 0.1, Wk=rng.normal(size=(d, d)) * 0.2,
+                   bk=rng.normal(size=d) * 0.1, Wv=rng.normal(size=(d, d)) * 0.2, bv=rng.normal(size=d) * 0.1,
+                   W1=rng.normal(size=(d, 24)) * 0.2, b1=rng.normal(size=24) * 0.1, W2=rng.normal(size=(24, d)) * 0.2,
+                   b2=rng.normal(size=d) * 0.1, ln1_g=np.ones(d), ln1_b=np.zeros(d), ln2_g=np.ones(d), ln2_b=np.zeros(d))
+
+        def batch(r):
+            r2 = np.random.default_rng(100 + r)
+            lens = r2.integers(0, S + 1, size=B)
+            seq = r2.integers(1, V, size=(B, S))
+            seq[np.arange(S)[None, :] < (S - lens)[:, None]] = 0
+            return seq.astype(np.int32), r2.integers(0, V, size=(B, 1)).astype(np.int32), \
+                r2.integers(0, V, size=(B, n_neg)).astype(np.int32)
+
+        # ---- the product path: one exchange forward, one back ----------------------------------------------------
+        st = OracleShardedTables([shard_table(torch.from_numpy(t.astype(np.float32)), rank, world) for t in T], [V] * 3,
+                                 rank, world)
+        seq, pos, neg = batch(rank)
+        ts, tp, tn = (torch.from_numpy(a) for a in (seq, pos, neg))
+        vids = torch.cat([st.virtual_ids(0, ts, pad_id=0).reshape(-1), st.virtual_ids(1, tp).reshape(-1),
+                          st.virtual_ids(2, tn).reshape(-1)])
+        rows, uidx, plan = st.lookup_rows(vids, keep_plan=True)
+        E = torch.where((uidx >= 0)[:, None], rows[uidx.clamp(min=0).long()], torch.zeros(1)).double().requires_grad_(True)
+        Pw = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in blk.items()}
+        seq_e = E[:B * S].view(B, S, d)
+        mask = torch.from_numpy((seq != 0).astype(np.float64))
+        x = ref_torch.encoder(seq_e * mask[..., None], mask, Pw, 1) * mask[..., None]
+        si = x[:, -1][:, None, :]
+        pos_e, neg_e = E[B * S:B * S + B].view(B, 1, d), E[B * S + B:].view(B, n_neg, d)
+        pl, nl = (si * pos_e).sum(-1), (si * neg_e).sum(-1)
+        loss = ((-torch.log(torch.sigmoid(pl)) - torch.log(1 - torch.sigmoid(nl))) / 2).mean()     # :93-95, (B,1)+(B,n)
+        (loss / world).backward()
+        grad_arena = torch.zeros_like(st.arena)
+        st.backward(plan, E.grad.float(), grad_arena)
+        dense = torch.cat([Pw[k].grad.reshape(-1) for k in sorted(Pw)]).float()
+        st.allreduce_sum_(dense)
+
+        # ---- the oracle: global mean loss on the unsharded tables ---------------------------------------------------
+        Tt = [torch.tensor(t.astype(np.float32).astype(np.float64), requires_grad=True) for t in T]
+        Pf = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in blk.items()}
+        tot = 0.0
+        for r in range(world):
+            sq, ps, ng = batch(r)
+            _, l_r = ref_torch.sasrec(sq, ps, ng, Tt[0], Tt[1], Tt[2], [Pf], 1)
+            tot = tot + l_r / world
+        tot.backward()
+        ok = True
+        for f in range(3):
+            mine = grad_arena[f * st.rows_local: f * st.rows_local + len(range(rank, V, world))].numpy()
+            ok = ok and bool(np.allclose(mine, Tt[f].grad.numpy()[rank::world], rtol=1e-5, atol=1e-7))
+        edense = torch.cat([Pf[k].grad.reshape(-1) for k in sorted(Pf)]).numpy()
+        ok = ok and bool(np.allclose(dense.numpy(), edense, rtol=1e-5, atol=1e-7))
+        ok = ok and all(not s.busy for s in st._slots)                  # the kept plan released its receive slot
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sasrec_training_through_the_exchange_gloo():
+    ret = _spawn(_sasrec_train_worker, 2, 300, 12, 6, 10)
+    assert all(ret.get(r) for r in range(2)), ret

@@ -101,9 +101,9 @@ def test_sasrec_config5_full_size(dev, monkeypatch):
     assert torch.equal(logits, m([seq, pos, neg]))                       # the one-launch kernel is deterministic
     assert bool((logits[0] == 0).all())                                  # all-padding sequence: logits exactly 0
     # the one-launch kernel against the layer-by-layer path on a slice
-    monkeypatch.setenv("REC_SASREC_IMPL", "layers")
+    m.fused = False
     layers = m([seq[:256], pos[:256], neg[:256]])
-    monkeypatch.delenv("REC_SASREC_IMPL")
+    m.fused = True
     assert close(logits[:256].cpu().numpy(), layers.cpu().numpy(), 1e-5)
     # subset vs the numpy oracle on compacted tables
     rows = np.concatenate([[0], np.random.default_rng(1).choice(np.arange(1, B), size=47, replace=False)])
@@ -137,9 +137,9 @@ def test_autoint_config3_full_size(dev, monkeypatch):
     m.set_weights(w)
     out = m([dense, ids])
     assert torch.equal(out, m([dense, ids]))
-    monkeypatch.setenv("REC_AUTOINT_IMPL", "layers")
+    m.fused = False
     out_layers = m([dense[:512], ids[:512]])
-    monkeypatch.delenv("REC_AUTOINT_IMPL")
+    m.fused = True
     assert close(out[:512].cpu().numpy(), out_layers.cpu().numpy())
     rows = np.random.default_rng(2).choice(B, size=128, replace=False)
     ridx = torch.from_numpy(rows).to(dev)

@@ -142,9 +142,9 @@ def test_autoint_one_launch_forward(dev, monkeypatch, B, nd, F, heads, L, res):
     m([dense, ids])
     w = randomize(m, rng, 0.2)
     out = m([dense, ids]).cpu().numpy()
-    monkeypatch.setenv("REC_AUTOINT_IMPL", "layers")
+    m.fused = False
     out_layers = m([dense, ids]).cpu().numpy()
-    monkeypatch.delenv("REC_AUTOINT_IMPL")
+    m.fused = True
     tables = [w[f'embed_{i}/embeddings'] for i in range(F)]
     emb = ref.gather_concat([t.astype(np.float64) for t in tables], ids).reshape(B, F, 16)
     x3 = emb if nd == 0 else np.concatenate(

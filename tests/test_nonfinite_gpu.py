@@ -5,7 +5,7 @@ representable weight), so the CONTRACT these tests pin is:
   * a +-inf / NaN input never turns into a wrong FINITE output: every output that depends on it is non-finite;
   * outputs that do not depend on it are bit-identical to the run without it (no contamination across rows / samples);
   * fp32 denormals are handled to within their own magnitude (low parts flush: |err| <= K * 2^-126), never as NaN;
-  * the fp32 kernels (REC_DENSE_IMPL=f, REC_MHA_IMPL=f) and the fused gather + pairwise-dot (fp32 MFMA, an fmaf chain)
+  * the fp32 kernels (forced "dense" "f", "mha" "f") and the fused gather + pairwise-dot (fp32 MFMA, an fmaf chain)
     keep exact IEEE behaviour — tests/test_pairwise_dot_gpu.py::test_ring_kernel_order_kat_and_nonfinite."""
 import numpy as np
 import pytest
@@ -19,14 +19,14 @@ def G(a, dev):
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
-def test_dense_bf16x3_nonfinite_rows(dev, monkeypatch, bad):
+def test_dense_bf16x3_nonfinite_rows(dev, force, bad):
     from recamd import ops
     rng = np.random.default_rng(1)
     M, K, N = 2048, 256, 128                         # the prepared-weights bf16x3 path
     x = rng.normal(size=(M, K)).astype(np.float32)
     W = (rng.normal(size=(K, N)) / 16).astype(np.float32)
     W[7, :] = 0.5                                     # exactly representable in bf16: its m / l terms are 0
-    monkeypatch.setenv("REC_DENSE_IMPL", "b")
+    force("dense", "b")
     clean = ops.dense(G(x, dev), G(W, dev)).cpu().numpy()
     xb = x.copy()
     xb[100, 7] = bad
@@ -36,7 +36,7 @@ def test_dense_bf16x3_nonfinite_rows(dev, monkeypatch, bad):
     rest = np.ones(M, bool)
     rest[[100, 1500]] = False
     assert np.array_equal(got[rest].view(np.uint32), clean[rest].view(np.uint32))
-    monkeypatch.setenv("REC_DENSE_IMPL", "f")         # the fp32-MFMA kernel: IEEE fp32 semantics
+    force("dense", "f")         # the fp32-MFMA kernel: IEEE fp32 semantics
     gf = ops.dense(G(xb, dev), G(W, dev)).cpu().numpy()
     if np.isnan(bad):
         assert np.isnan(gf[100]).all()
@@ -44,7 +44,7 @@ def test_dense_bf16x3_nonfinite_rows(dev, monkeypatch, bad):
         assert np.all(gf[100] == bad) and np.all(np.isinf(gf[1500]))
 
 
-def test_dense_bf16x3_denormals(dev, monkeypatch):
+def test_dense_bf16x3_denormals(dev, force):
     from recamd import ops
     rng = np.random.default_rng(2)
     M, K, N = 1024, 128, 64
@@ -52,7 +52,7 @@ def test_dense_bf16x3_denormals(dev, monkeypatch):
     W = (rng.normal(size=(K, N)) / 8).astype(np.float32)
     x[:, :16] = (rng.random((M, 16)) * 1e-39).astype(np.float32)       # fp32 denormals
     W[:8, :] = (rng.random((8, N)) * 1e-40).astype(np.float32)
-    monkeypatch.setenv("REC_DENSE_IMPL", "b")
+    force("dense", "b")
     got = ops.dense(G(x, dev), G(W, dev)).cpu().numpy()
     exp = x.astype(np.float64) @ W.astype(np.float64)
     assert np.isfinite(got).all()

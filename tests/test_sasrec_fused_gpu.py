@@ -112,7 +112,7 @@ def test_strided_ids_and_pad_id_minus_one(dev):
 
 
 def test_model_paths_agree(dev, monkeypatch):
-    """The mirror's one-launch path equals its layer-by-layer path (REC_SASREC_IMPL=layers) on the same weights."""
+    """The mirror's one-launch path equals its layer-by-layer path (`fused = False`) on the same weights."""
     from match.sasrec.model import SASRec
     rng = np.random.default_rng(8)
     V, S, n, B = 500, 200, 100, 300
@@ -128,7 +128,7 @@ def test_model_paths_agree(dev, monkeypatch):
     neg = rng.integers(1, V, size=(B, n)).astype(np.int32)
     a = m([seq, pos, neg]).cpu().numpy()
     emb_a = m.embed.cpu().numpy()
-    monkeypatch.setenv("REC_SASREC_IMPL", "layers")
+    m.fused = False
     b = m([seq, pos, neg]).cpu().numpy()
     assert close(a, b, 1e-5) and close(emb_a, m.embed.cpu().numpy(), 1e-5)
 

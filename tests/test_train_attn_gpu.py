@@ -283,12 +283,9 @@ def test_autoint_training_step(dev, use_res, layers, H):
     dense = rng.random((B, nd)).astype(np.float32)
     ids = np.stack([rng.integers(0, V + i, size=B) for i in range(F)], axis=1).astype(np.int32)
     y = (rng.random(B) < 0.4).astype(np.float32)
-    import os
-    os.environ['REC_AUTOINT_IMPL'] = 'layers'
-    try:
-        m([dense, ids])                        # builds the lazily created layers
-    finally:
-        del os.environ['REC_AUTOINT_IMPL']
+    m.fused = False
+    m([dense, ids])                            # builds the lazily created layers
+    m.fused = True
     randomize(m, rng, 0.3)
     l2 = run_steps(m, "autoint", {"H": H, "S": S, "use_res": use_res}, [dense, ids], y)
     assert l2["attention_0/Wq"] == 1e-4 and l2["/embeddings"] == 1e-4
@@ -379,6 +376,74 @@ def test_sasrec_training_step(dev, blocks, H, S):
         if k.endswith("gamma"):
             m.set_weights({k: (1 + 0.1 * rng.normal(size=v.shape)).astype(np.float32)})
     run_steps(m, "sasrec", {"n_blocks": blocks, "H": H}, [seq, pos, neg], None)
+
+
+def test_sasrec_row_sharded_training_matches_unsharded(dev):
+    """BASELINE configs[4], trained: G = 2 ranks (simulated in one process, tests/shard_oracle.py::PeersShardedTables),
+    tables row-sharded, every rank its own batch.  The lookups travel through the sharded exchange, their gradients
+    return to the owners (ShardedTables.backward), dense gradients are all-reduced, tables are not.  After two Adam
+    steps every rank's dense weights equal the unsharded model's trained on the concatenated batch (itself pinned to
+    the fp64 autograd oracle by test_sasrec_training_step), and its table shards equal rows r::G of the full tables."""
+    from match.sasrec.model import SASRec
+    from recamd import train as tr
+    from recamd.dist import shard_table
+    from tests.shard_oracle import PeersShardedTables
+    from tests.test_models_gpu import randomize
+    rng = np.random.default_rng(77)
+    G, B, S, d, n_neg, V = 2, 16, 6, 16, 5, 30
+    cols = [{'feat': k, 'feat_num': V, 'feat_len': n, 'embed_dim': d} for k, n in
+            (('seq_item', S), ('pos_item', 1), ('neg_item', n_neg))]
+    kw = dict(blocks=1, num_heads=1, att_hidden_unit=d, ffn_hidden_unit=24, seq_len=S, neg_len=n_neg, embed_reg=1e-4,
+              last_row_only=False)
+
+    def batch(r):
+        g = np.random.default_rng(500 + r)
+        seq = g.integers(1, V, size=(B, S)).astype(np.int32)
+        for b in range(B):
+            seq[b, :g.integers(0, S)] = 0
+        return [seq, g.integers(1, V, size=(B, 1)).astype(np.int32), g.integers(1, V, size=(B, n_neg)).astype(np.int32)]
+    batches = [batch(r) for r in range(G)]
+    glob = [np.concatenate([batches[r][i] for r in range(G)]) for i in range(3)]
+    full = SASRec(cols, [], **kw)
+    full(glob)
+    randomize(full, rng, 0.3)
+    w0 = full.get_weights()
+    names = [f"user_embed_{k}/embeddings" for k in ("seq_item", "pos_item", "neg_item")]
+    ranks = [SASRec(cols, [], sharded=(r, G), shard_factory=PeersShardedTables, **kw) for r in range(G)]
+    for m in ranks:
+        m._sharded.link_peers([x._sharded for x in ranks])
+    for r, m in enumerate(ranks):
+        m(batches[r])                                        # builds the lazily created layers (and sizes the receive slots)
+        ws = {k: v for k, v in w0.items() if k not in names}
+        for n in names:
+            ws[n] = shard_table(torch.from_numpy(w0[n]), r, G).numpy()
+        m.set_weights(ws)
+    lr = 1e-2
+    opt_f, st_f = tr.Adam(full, lr, l2=tr.default_l2(full)), tr.TrainState(full)
+    opts = [tr.Adam(m, lr, l2=tr.default_l2(m)) for m in ranks]
+    states = [tr.TrainState(m) for m in ranks]
+    for r, m in enumerate(ranks):                            # the owners' gradient arenas exist before anyone sends into them
+        m._sharded.peer_grad_arena = states[r].sharded_grad(m._sharded, names)
+    for _step in range(2):
+        tr.train_step(full, opt_f, st_f, glob, None)
+        outs = [tr.compute_gradients(m, st, batches[r], None, 1.0 / G) for r, (m, st) in enumerate(zip(ranks, states))]
+        for k in sorted(outs[0][2]):                         # the all-reduce of the dense gradients, by hand
+            tot = outs[0][2][k] + outs[1][2][k]
+            for o in outs:
+                o[2][k] = tot.clone()
+        for r in range(G):
+            assert states[r].owner_summed == set(names)      # the tables' gradients arrived summed: no all-reduce for them
+            opts[r].apply(outs[r][2], states[r])
+    wf = {k: v.detach().cpu().numpy() for k, v in tr.named_weights(full).items()}
+    for r, m in enumerate(ranks):
+        wr = {k: v.detach().cpu().numpy() for k, v in tr.named_weights(m).items()}
+        for k, v in wr.items():
+            e = wf[k][r::G] if k in names else wf[k]
+            assert v.shape == e.shape, k
+            dd = np.abs(v - e)       # as check_weights: Adam amplifies rounding where |g| ~ eps
+            band = 1e-5 * np.maximum(np.abs(e), 1e-2) + 1e-3 * lr
+            assert (dd > band).mean() <= 2e-3 and dd.max() <= 1e-2 * lr * 2, (k, r, float(dd.max()), int((dd > band).sum()))
+        assert all(not s.busy for s in m._sharded._slots)    # every kept plan released its receive slot
 
 
 def test_sasrec_fit_without_labels(dev):

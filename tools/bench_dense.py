@@ -1,6 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "recommend-tf2.0_amd"))
 from recamd import ops
+from recamd._lib import C
 dev = torch.device("cuda:0")
 def t(fn, it=20):
     for _ in range(3): fn()
@@ -14,11 +15,11 @@ for (M, K, N) in [(1638400, 64, 64), (1638400, 64, 128), (1638400, 128, 64), (65
     x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev); b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
     ms = t(lambda: ops.dense(x, W, b, "relu", out=out))
-    os.environ["REC_DENSE_IMPL"] = "t"
+    C.debug_force("dense", "t")
     ms_t = t(lambda: ops.dense(x, W, b, "relu", out=out))
-    os.environ["REC_DENSE_IMPL"] = "b"
+    C.debug_force("dense", "b")
     ms_b = t(lambda: ops.dense(x, W, b, "relu", out=out))
-    del os.environ["REC_DENSE_IMPL"]
+    C.debug_force("dense", None)
     ms_torch = t(lambda: torch.relu(torch.addmm(b, x, W)))
     fl = 2.0 * M * K * N
     by = 4.0 * (M * K + M * N + K * N)

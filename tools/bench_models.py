@@ -1,5 +1,5 @@
 """Model-level forward throughput on one MI355X at the BASELINE headline shape (65 536 x 26 sparse x dim 128), with
-the paper-sized DLRM MLPs, for the default build and with REC_DENSE_IMPL=f (fp32-MFMA Dense) — i.e. what the
+the paper-sized DLRM MLPs, for the default build and with rec_debug_force("dense", "f") (fp32-MFMA Dense) — i.e. what the
 bf16x3 Dense buys end to end.  Tables use V = 200 000 rows per field to leave HBM for several models."""
 import json
 import os
@@ -10,6 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recommend-tf2.0_amd"))
+from recamd._lib import C  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, F, D, V, ND = 65536, 26, 128, 200_000, 13
@@ -54,12 +55,12 @@ def main():
         row = {}
         for impl in ("default", "f"):
             if impl == "f":
-                os.environ["REC_DENSE_IMPL"] = "f"
+                C.debug_force("dense", "f")
             else:
-                os.environ.pop("REC_DENSE_IMPL", None)
+                C.debug_force("dense", None)
             ms = timeit(lambda: m(x))
             row[impl] = {"forward_ms": round(ms, 3), "samples_per_s": round(B / ms * 1e3)}
-        os.environ.pop("REC_DENSE_IMPL", None)
+        C.debug_force("dense", None)
         row["speedup_from_bf16x3_dense"] = round(row["f"]["forward_ms"] / row["default"]["forward_ms"], 2)
         res[name] = row
         print(json.dumps({name: row}), flush=True)
