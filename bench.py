@@ -111,6 +111,8 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=16384)
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (gather_roofline, rowshard)")
     ap.add_argument("--side-timeout", type=float, default=150.0, help="watchdog of the N>1 side placement measurement (s)")
+    ap.add_argument("--force", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B only: rec_debug_force(KEY, VALUE) before the workload is built (kernel variants a shape would not select)")
     ap.add_argument("--side-leg", action="store_true", help=argparse.SUPPRESS)   # internal: child process of an N>1 run
     return ap.parse_args()
 
@@ -282,7 +284,7 @@ def wl_din(torch, dev, a, rank, world):
             "pmc_key": "din_gather_pool_grp_kernel",
             "workload": "DIN var-len user history (max 100) attention pooling, batch 8192" +
                         (" (BASELINE configs[3])" if (Dt, B, T) == (64, 8192, 100) else ", %d tables x width %d" % (ntab, Dt)),
-            "config": {"batch_per_gpu": B, "global_batch": B * world, "maxlen": T, "d": d, "vocab_per_table": V,
+            "config": {"batch_per_gpu": B, "global_batch": B * world, "maxlen": T, "d": d, "tables": ntab, "width": Dt, "vocab_per_table": V,
                        "mean_real_slots": round(real_slots / NB / B, 2),
                        "bytes_note": "rows of real (non-pad) history slots only + all ids + q + out"},
             "side_gather": None, "shape_cfg": {"workload": "din", "batch": B, "vocab": V, "ids": a.ids, "width": Dt}}
@@ -483,6 +485,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev, control_backend = init_ranks(torch, dist, a, world, rank, local_rank)
+    if a.force:
+        from recamd._lib import C
+        for kv in a.force:
+            k, _, v = kv.partition("=")
+            C.debug_force(k, v)
 
     def barrier():
         if world > 1:

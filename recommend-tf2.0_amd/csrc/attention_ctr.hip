@@ -319,7 +319,8 @@ __device__ __forceinline__ void stage_weights(f32x4* __restrict__ wl, const floa
 template <int NT, int KS0, int H, int ACT, bool IO = false>
 // (wider shapes — NT = 4 or din = 32 with two heads — would spill 26-62 registers under that budget: they keep two)
 __global__ __launch_bounds__(256, (NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2) void mha_ctr_stack_kernel(const float* __restrict__ x, int64_t B, int N, CtrStackArgs wa,
-                                                            int L, int act, float* __restrict__ out, CtrFusedIo io = {}) {
+                                                            int L, int act, float* __restrict__ out, CtrFusedIo io = {},
+                                                            int cus = 0, int stagger = 0) {
   using namespace cf32;
   extern __shared__ __attribute__((aligned(16))) f32x4 wstack[];
   constexpr int din0 = 16 * KS0, HS = 16 * H;
@@ -330,10 +331,14 @@ __global__ __launch_bounds__(256, (NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2)
   __syncthreads();
   const int lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // persistent over samples: b = wave + k * waves (weights are staged once per workgroup)
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t b = (int64_t)blockIdx.x * 4 + (tid >> 6); b < B; b += nwaves) {
-    f32x4 x0[NT][KS0];
+  // A/B knob (rec_debug_force("autoint_stagger", n)): the workgroups that share a CU start n x 1024 cycles apart, so the
+  // waves of a SIMD are not all in their matrix phase (or all in their softmax phase) at the same time
+  if (stagger > 0 && cus > 0) {
+    const int slot = (int)(blockIdx.x / (unsigned)cus);
+    for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  // the sample's rows in operand layout: lane (field, g) holds x[field][16 ks + 4g .. + 3]
+  auto load_x0 = [&](int64_t b, f32x4(&x0)[NT][KS0]) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       const int n = rt * 16 + lr;
@@ -356,6 +361,25 @@ __global__ __launch_bounds__(256, (NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2)
           x0[rt][ks] = n < N ? *reinterpret_cast<const f32x4*>(x + (b * N + n) * (int64_t)din0 + 16 * ks + 4 * g) : zero;
         }
       }
+    }
+  };
+  // persistent over samples: b = wave + k * waves (weights are staged once per workgroup).  The NEXT sample's rows are
+  // requested before this sample's layers run (id -> row is two dependent HBM round trips; 12 registers at NT = 3, din 16)
+  constexpr bool kPrefetch = (NT <= 3 && KS0 == 1);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t b = (int64_t)blockIdx.x * 4 + (tid >> 6);
+  f32x4 xn[NT][KS0];
+  if (kPrefetch && b < B) load_x0(b, xn);
+  for (; b < B; b += nwaves) {
+    f32x4 x0[NT][KS0];
+    if constexpr (kPrefetch) {
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) x0[rt][ks] = xn[rt][ks];
+      if (b + nwaves < B) load_x0(b + nwaves, xn);
+    } else {
+      load_x0(b, x0);
     }
     f32x4 ya[NT][H], yb[NT][H];
     ctr_layer<NT, KS0, H, ACT>(x0, wstack, wa.W0[0] != nullptr, act, N, lr, g, ya);
@@ -421,20 +445,21 @@ bool mha_ctr_stack_dispatch(const float* x, int64_t B, int N, int din, const Ctr
   const int wg_res = wg_per_cu > 0 ? wg_per_cu : ((NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2);   // as the kernel's launch bounds
   if (blocks > (int64_t)cus * wg_res) blocks = (int64_t)cus * wg_res;
   const dim3 grid((unsigned)blocks), block(256);
+  const int stagger = forced("autoint_stagger") ? atoi(forced("autoint_stagger")) : 0;
 #define REC_CST(NT_, KS_, H_)                                                                                       \
   do {                                                                                                              \
     if (io && act == REC_ACT_RELU)                                                                                  \
       hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, REC_ACT_RELU, true>), grid, block, lds, st, x, B, N, wa, L, \
-                         act, out, *io);                                                                            \
+                         act, out, *io, cus, stagger);                                                              \
     else if (io)                                                                                                    \
       hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, -1, true>), grid, block, lds, st, x, B, N, wa, L, act, out, \
-                         *io);                                                                                      \
+                         *io, cus, stagger);                                                                        \
     else if (act == REC_ACT_RELU)                                                                                   \
       hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, REC_ACT_RELU>), grid, block, lds, st, x, B, N, wa, L, act, \
-                         out, CtrFusedIo{});                                                                        \
+                         out, CtrFusedIo{}, cus, stagger);                                                          \
     else                                                                                                            \
       hipLaunchKernelGGL((mha_ctr_stack_kernel<NT_, KS_, H_, -1>), grid, block, lds, st, x, B, N, wa, L, act, out,  \
-                         CtrFusedIo{});                                                                             \
+                         CtrFusedIo{}, cus, stagger);                                                               \
   } while (0)
 #define REC_CST_NT(KS_, H_)              \
   do {                                   \

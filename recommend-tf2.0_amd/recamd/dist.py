@@ -557,7 +557,7 @@ class ShardedTables:
         uidx = p.uidx if self.transport != "cabi" else p.uidx.clone()    # the slot's workspace is reused; the index is small
         if keep_plan:
             p.uidx = uidx
-            p.recv_local = p.recv_local.clone()     # the shared serve buffer is rewritten by the next exchange
+            p.recv_local = None if p.recv_local is None else p.recv_local.clone()     # the shared serve buffer is rewritten by the next exchange
             return self.space, uidx, p
         self._release(p)
         return self.space, uidx
@@ -574,7 +574,7 @@ class ShardedTables:
         self._ready(p)
         out = self._dev_consume_concat(p.uidx, B, out, oob_flag)
         if keep_plan:
-            p.recv_local = p.recv_local.clone()     # the shared serve buffer is rewritten by the next exchange
+            p.recv_local = None if p.recv_local is None else p.recv_local.clone()     # the shared serve buffer is rewritten by the next exchange
             return out, p
         self._release(p)
         return out

@@ -252,6 +252,19 @@ def gather_concat_fwd(tape: Tape, state: "TrainState", group: ops.TableGroup, na
     return y
 
 
+def concat_cols(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """tf.concat(parts, axis=-1) of 2-D tensors as column-offset writes into one buffer (rec_copy2d_f32) — the way the
+    inference mirrors build their concat buffers; no ATen cat on the training path"""
+    B = parts[0].shape[0]
+    out = torch.empty((B, sum(int(t.shape[1]) for t in parts)), dtype=torch.float32, device=parts[0].device)
+    c = 0
+    for t in parts:
+        w = int(t.shape[1])
+        ops.copy_cols(t if t.stride(1) == 1 else t.contiguous(), out[:, c:c + w])
+        c += w
+    return out
+
+
 def gather_pairwise_dot_fwd(tape: Tape, state: "TrainState", group: ops.TableGroup, names: Sequence[str],
                             ids: torch.Tensor, dense: Var) -> Var:
     z = Var(ops.gather_pairwise_dot(group, ids, dense.v, append_dense=True))
@@ -468,9 +481,18 @@ def dlrm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_sc
     if m.interaction == "dot":
         x = gather_pairwise_dot_fwd(tape, state, m._group, names, ids, dense_fea)
     else:
-        emb = gather_concat_fwd(tape, state, m._group, names, ids)
+        # tf.concat([sparse_embed, dense_fea]) (:48): the gather writes its columns of the concat buffer in place
         W = m._group.width
-        x = Var(torch.cat([emb.v, dense_fea.v], dim=-1))
+        buf = torch.empty((ids.shape[0], W + dense_fea.v.shape[1]), dtype=torch.float32, device=m.device)
+        ops.gather_concat(m._group, ids, out=buf)
+        ops.copy_cols(dense_fea.v, buf[:, W:])
+        x = Var(buf)
+        emb = Var(buf[:, :W])
+
+        def bwd_gather():
+            if emb.g is not None:
+                ops.embedding_grad(_grad_group(None, m._group, names, state), ids, emb.g)
+        tape.ops.append(bwd_gather)
 
         def bwd():
             emb.acc(x.g[:, :W].contiguous())
@@ -488,7 +510,7 @@ def deepfm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_
     names = _embed_names(len(m._group))
     plain = ops.TableGroup(m._group.tables)                                 # tf.concat offsets 0, D, 2D, ...
     sparse_embed = gather_concat_fwd(tape, state, plain, names, ids)        # :53
-    embeds = Var(torch.cat([dense_inputs, sparse_embed.v], dim=-1))         # :56
+    embeds = Var(concat_cols([dense_inputs, sparse_embed.v]))              # :56
     nd = dense_inputs.shape[1]
 
     def bwd_cat():
@@ -506,7 +528,7 @@ def dcn_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_sca
     x = gather_concat_fwd(tape, state, ops.TableGroup(m._group.tables), names, ids)      # :47
     cross_x = cross_fwd(tape, m.cross_network, "cross_network", x)                        # :51
     dnn_x = dnn_fwd(tape, m.dnn_network, "dnn_network", x)                                # :53
-    total = Var(torch.cat([cross_x.v, dnn_x.v], dim=-1))                                 # :55
+    total = Var(concat_cols([cross_x.v, dnn_x.v]))                                       # :55
     wc = cross_x.v.shape[1]
 
     def bwd():

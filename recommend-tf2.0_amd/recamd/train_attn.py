@@ -16,7 +16,7 @@ import torch
 
 from . import nn, ops
 from ._lib import C
-from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, dense_fwd, sigmoid_bce, transpose,
+from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, concat_cols, dense_fwd, sigmoid_bce, transpose,
                     weight_grad)
 
 
@@ -212,7 +212,7 @@ def autoint_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad
         nd = E.shape[0]
         dpart = torch.empty((B, nd * D), dtype=torch.float32, device=m.device)
         ops.scale_embed(dense_inputs, E, dpart)
-        h = h0 = Var(torch.cat([emb.v, dpart], dim=1).view(B, F + nd, D))
+        h = h0 = Var(concat_cols([emb.v, dpart]).view(B, F + nd, D))
 
         def bwd_cat():          # `h` is rebound by the layer loop below: the closure keeps its own name
             g = h0.g.contiguous().view(B, (F + nd) * D)
@@ -274,7 +274,7 @@ def din_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_sca
     att = din_pool_fwd(tape, m.attention_layer, "attention_layer", item_emb, beh, mask)
     parts = [Var(user_dense), user_emb, Var(item_sparse.contiguous()), item_emb, att]                  # :62-68, :81
     widths = [p.v.shape[1] for p in parts]
-    allv = Var(torch.cat([p.v for p in parts], dim=-1))
+    allv = Var(concat_cols([p.v for p in parts]))
 
     def bwd_cat():
         off = 0
@@ -428,7 +428,7 @@ def scale_fwd(tape: Tape, x: Var, c: float) -> Var:
 
 def concat_fwd(tape: Tape, parts: Sequence[Var]) -> Var:
     """tf.concat(parts, axis=-1) of 2-D activations; every part receives its column slice of the gradient"""
-    y = Var(torch.cat([p.v for p in parts], dim=-1))
+    y = Var(concat_cols([p.v for p in parts]))
     widths = [p.v.shape[1] for p in parts]
 
     def bwd():
