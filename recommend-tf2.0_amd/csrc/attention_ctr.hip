@@ -211,6 +211,23 @@ namespace cf32 {
 // fix-up), the sqrt(S) log2(e) factor folded into Q once per element instead of once per score, the 1/sum applied to
 // the 4 output registers instead of the 12 probabilities, the key mask only on the last key tile, relu as a compile-time
 // case.
+// All-reduce over the wave's four 16-lane rows (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: gfx950's v_permlane32_swap
+// (upper half of one register <-> lower half of the other) and v_permlane16_swap (odd rows <-> even rows) exchange the
+// halves in registers.  __shfl_xor(v, 16 | 32) compiles to ds_bpermute_b32, an LDS-pipe round trip, and the softmax has
+// four of them in its dependency chain per (head, query tile): max -> exp -> sum -> 1/sum.
+__device__ __forceinline__ float rows_max(float v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_ct(float v, int act) {
   if constexpr (ACT == REC_ACT_RELU) return relu_nan(v);
@@ -265,8 +282,7 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
 #pragma unroll
         for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sc[kt][r]);
       }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      mloc = rows_max(mloc);
       float lsum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt)
@@ -276,9 +292,8 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
           sc[kt][r] = p;
           lsum += p;
         }
-      lsum += __shfl_xor(lsum, 16, 64);
-      lsum += __shfl_xor(lsum, 32, 64);
-      const float inv = 1.f / lsum;
+      lsum = rows_sum(lsum);
+      const float inv = __builtin_amdgcn_rcpf(lsum);   // v_rcp_f32 (1 ulp; lsum in [1, N]) instead of the IEEE division sequence
       f32x4 o = zero;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) o = mfma4(vf[kt], sc[kt], o);   // O^T = V^T P^T (unnormalised)
@@ -363,24 +378,14 @@ __global__ __launch_bounds__(256, (NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2)
       }
     }
   };
-  // persistent over samples: b = wave + k * waves (weights are staged once per workgroup).  The NEXT sample's rows are
-  // requested before this sample's layers run (id -> row is two dependent HBM round trips; 12 registers at NT = 3, din 16)
-  constexpr bool kPrefetch = (NT <= 3 && KS0 == 1);
+  // persistent over samples: b = wave + k * waves (weights are staged once per workgroup).  (Round 3 A/B: requesting the
+  // NEXT sample's rows before this sample's layers costs 12 more registers under the 168 cap — 14 spilled instead of 2 —
+  // and runs 80.2 us against 76.8; starting the workgroups of a CU 2-16 k cycles apart: 80.6-83.5 us.  Neither the
+  // input latency nor phase lockstep is what the kernel waits for: profiles/r03_autoint_ab.txt.)
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  int64_t b = (int64_t)blockIdx.x * 4 + (tid >> 6);
-  f32x4 xn[NT][KS0];
-  if (kPrefetch && b < B) load_x0(b, xn);
-  for (; b < B; b += nwaves) {
+  for (int64_t b = (int64_t)blockIdx.x * 4 + (tid >> 6); b < B; b += nwaves) {
     f32x4 x0[NT][KS0];
-    if constexpr (kPrefetch) {
-#pragma unroll
-      for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < KS0; ++ks) x0[rt][ks] = xn[rt][ks];
-      if (b + nwaves < B) load_x0(b + nwaves, xn);
-    } else {
-      load_x0(b, x0);
-    }
+    load_x0(b, x0);
     f32x4 ya[NT][H], yb[NT][H];
     ctr_layer<NT, KS0, H, ACT>(x0, wstack, wa.W0[0] != nullptr, act, N, lr, g, ya);
     for (int l = 1; l < L; ++l) {   // ping-pong in registers

@@ -81,5 +81,5 @@ class DCN(Model):
             self.dnn_network(x, out=total[:, dim:dim + H])                                    # :53
             total_x = total[:, :dim + H]
         else:
-            total_x = torch.cat([total[:, :dim], self.dnn_network(x)], dim=-1)
+            total_x = ops.concat_cols([total[:, :dim], self.dnn_network(x)])
         return ops.add_sigmoid(self.dense_final(total_x))                  # :56

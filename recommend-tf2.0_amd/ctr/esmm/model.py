@@ -63,7 +63,7 @@ class ESMM(Model):
     def _tower(self, head, un, uc, inum, ic):
         user_feature = self.user_dnn(self._tower_input(un, uc, self._user_group, self._user_cols))   # :53
         item_feature = self.item_dnn(self._tower_input(inum, ic, self._item_group, self._item_cols))  # :54
-        return head(torch.cat([user_feature, item_feature], dim=-1))                                  # :56-61
+        return head(ops.concat_cols([user_feature, item_feature]))                                  # :56-61
 
     def call(self, inputs, **kwargs):
         (ctr_un, ctr_uc, ctr_in, ctr_ic, cvr_un, cvr_uc, cvr_in, cvr_ic) = inputs

@@ -37,8 +37,8 @@ class NCF(Model):
         dim = user.shape[1]
         u = user[:, None, :].expand(B, T, dim).reshape(B * T, dim).contiguous()        # tf.tile (:63)
         gmf = ops.mul_act(u, item, 'sigmoid')                                            # :53-54
-        mlp = self.dnn(torch.cat([u, item], dim=-1))                                     # :61-66
-        return self.dense(torch.cat([gmf, mlp], dim=-1)).reshape(B, T)                   # :69-73
+        mlp = self.dnn(ops.concat_cols([u, item]))                                     # :61-66
+        return self.dense(ops.concat_cols([gmf, mlp])).reshape(B, T)                   # :69-73
 
     def call(self, inputs, training=None, mask=None):
         user_inputs, pos_inputs, neg_inputs = inputs
@@ -47,7 +47,7 @@ class NCF(Model):
         neg, _, Tn = self._lookup(self.neg_item_embedding, neg_inputs)
         pos_logits = self._branch(user, pos, B, Tp)
         neg_logits = self._branch(user, neg, B, Tn)
-        self._logits = torch.cat([pos_logits, neg_logits], dim=-1)                      # :79
+        self._logits = ops.concat_cols([pos_logits, neg_logits])                      # :79
         return self._logits
 
     @property

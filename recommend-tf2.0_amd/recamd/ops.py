@@ -729,6 +729,19 @@ def copy_cols(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def concat_cols(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """tf.concat(parts, axis=-1) of 2-D fp32 tensors as column-offset writes into one buffer (rec_copy2d_f32): where a
+    producer kernel cannot write its columns in place, this is the copy — no ATen cat on any model path"""
+    B = parts[0].shape[0]
+    out = torch.empty((B, sum(int(t.shape[1]) for t in parts)), dtype=torch.float32, device=parts[0].device)
+    c = 0
+    for t in parts:
+        w = int(t.shape[1])
+        copy_cols(t if t.stride(1) == 1 else t.contiguous(), out[:, c:c + w])
+        c += w
+    return out
+
+
 def scale_embed(x: torch.Tensor, E: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out[b, j*D:(j+1)*D] = x[b, j] * E[j]  (out: a (B, >= nd*D) view at the column offset of the concat buffer)"""
     _rows2d(_chk(x, "x"), "x")

@@ -252,17 +252,7 @@ def gather_concat_fwd(tape: Tape, state: "TrainState", group: ops.TableGroup, na
     return y
 
 
-def concat_cols(parts: Sequence[torch.Tensor]) -> torch.Tensor:
-    """tf.concat(parts, axis=-1) of 2-D tensors as column-offset writes into one buffer (rec_copy2d_f32) — the way the
-    inference mirrors build their concat buffers; no ATen cat on the training path"""
-    B = parts[0].shape[0]
-    out = torch.empty((B, sum(int(t.shape[1]) for t in parts)), dtype=torch.float32, device=parts[0].device)
-    c = 0
-    for t in parts:
-        w = int(t.shape[1])
-        ops.copy_cols(t if t.stride(1) == 1 else t.contiguous(), out[:, c:c + w])
-        c += w
-    return out
+concat_cols = ops.concat_cols
 
 
 def gather_pairwise_dot_fwd(tape: Tape, state: "TrainState", group: ops.TableGroup, names: Sequence[str],
