@@ -53,7 +53,18 @@ constexpr int kWaves = REC_SASREC_WAVES;   // per workgroup (one workgroup per C
 #ifndef REC_SASREC_KU
 #define REC_SASREC_KU 4
 #endif
-constexpr int kU = REC_SASREC_KU;   // row-load instructions per landing buffer (4 rows each); two buffers per wave
+constexpr int kU = REC_SASREC_KU;   // row-load instructions per landing buffer (4 rows each)
+// landing buffers per wave (16 rows each at kU = 4).  Attention phase: the matvec chain's values are live beside them.
+// Candidate phase: almost nothing else is live, so more buffers fit the same register budget — and every buffer more is
+// 16 more rows in flight per wave, i.e. fewer HBM round trips in the sample's serial chain (round 3).
+#ifndef REC_SASREC_ATT_BUFS
+#define REC_SASREC_ATT_BUFS 2
+#endif
+#ifndef REC_SASREC_CAND_BUFS
+#define REC_SASREC_CAND_BUFS 2
+#endif
+constexpr int kNA = REC_SASREC_ATT_BUFS, kNC = REC_SASREC_CAND_BUFS;
+constexpr int kNB = kNA > kNC ? kNA : kNC;
 
 struct SasrecParams {
   const float *wq, *bq, *wk, *wv, *bv, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
@@ -148,6 +159,23 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
   // receives the next sample's ids), the candidate ids, two mask words
   int32_t* const wave_lds = reinterpret_cast<int32_t*>(vec + 7 * 64 + FH + kWaves * 64) + (threadIdx.x >> 6) * (2 * lst_cap + cand_cap + 2);
   const int tid = threadIdx.x;
+  const int lane_c = tid & 63, wave = tid >> 6;
+  const float scale_log2e = 1.4426950408889634f * 0.125f;   // log2(e) / sqrt(64)
+  const int n_cand = n_pos + n_neg;
+  int32_t* const cbuf = wave_lds + 2 * lst_cap;
+  int32_t* const msk = cbuf + cand_cap;
+  // LDS byte address of this wave's area (wave-uniform; readfirstlane tells the compiler so)
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)wave_lds);
+
+  // the first sample's ids leave before the weights are staged: their latency hides under the staging (round 3)
+  const int64_t bstep = (int64_t)gridDim.x * kWaves;
+  int64_t b = (int64_t)blockIdx.x * kWaves + wave;
+  auto prefetch_seq_ids = [&](int64_t bb, int which) {
+    for (int c = 0; c * 64 < S; ++c)
+      if (c * 64 + lane_c < S) glds4(seq_ids + bb * seq_stride + c * 64 + lane_c, lds0 + (uint32_t)(which * lst_cap + c * 64) * 4u);
+    if (lane_c == 0) glds4(mask_ids + bb * mask_stride, lds0 + (uint32_t)(2 * lst_cap + cand_cap + which) * 4u);
+  };
+  if (b < B) prefetch_seq_ids(b, 0);
   auto w4 = [](int i, int c, int ncol) { return ((i >> 2) * ncol + c) * 4 + (i & 3); };
   for (int e = tid; e < 64 * 64; e += kWaves * 64) {       // e = i * 64 + o of the Keras (in, out) kernels
     const int i = e >> 6, o = e & 63;
@@ -171,14 +199,6 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
   if (tid < FH) vec[448 + tid] = P.b1[tid];
   __syncthreads();
 
-  const int lane_c = tid & 63, wave = tid >> 6;
-  const float scale_log2e = 1.4426950408889634f * 0.125f;   // log2(e) / sqrt(64)
-  const int n_cand = n_pos + n_neg;
-  int32_t* const cbuf = wave_lds + 2 * lst_cap;
-  int32_t* const msk = cbuf + cand_cap;
-  // LDS byte address of this wave's area (wave-uniform; readfirstlane tells the compiler so)
-  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)wave_lds);
-
   // ---- per-sample pipeline ---------------------------------------------------------------------------------------
   // A wave's samples are a serial chain of memory round trips (ids -> rows -> ... -> candidate rows); with 16 waves per
   // CU that chain, not the bandwidth, set the first version's time (100 us).  So every fetch is issued as early as its
@@ -186,14 +206,6 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
   // prefetched value the compiler has to spill is a value it waits for); the last row and the first two row batches
   // before the Wq / Wk matvecs; row batch i + 2 as soon as batch i has been reduced (two landing buffers in
   // registers); the first two candidate batches before the Wv / LN / FFN chain (candidate rows do not depend on it).
-  const int64_t bstep = (int64_t)gridDim.x * kWaves;
-  int64_t b = (int64_t)blockIdx.x * kWaves + wave;
-  auto prefetch_seq_ids = [&](int64_t bb, int which) {
-    for (int c = 0; c * 64 < S; ++c)
-      if (c * 64 + lane_c < S) glds4(seq_ids + bb * seq_stride + c * 64 + lane_c, lds0 + (uint32_t)(which * lst_cap + c * 64) * 4u);
-    if (lane_c == 0) glds4(mask_ids + bb * mask_stride, lds0 + (uint32_t)(2 * lst_cap + cand_cap + which) * 4u);
-  };
-  if (b < B) prefetch_seq_ids(b, 0);
   int cur = 0;
   for (; b < B; b += bstep, cur ^= 1) {
     // everything lane-dependent below derives from a laundered lane index: otherwise the compiler hoists dozens of
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     const bool last_ok = id_last != pad_id && (uint32_t)id_last < (uint32_t)seq_vocab;
     // ---- issue: last row, row batches 0 and 1 ---------------------------------------------------------------------
     float x_last = seq_table[(int64_t)(last_ok ? id_last : 0) * kD + lane];
-    f32x4 ka[kU], kb[kU];
+    f32x4 kbuf[kNB][kU];
     // every issue is unconditional (rows past the end re-read the last real row: a cache hit): a conditional one makes
     // the landing buffers phi values and the register allocator answers with copies and spills
     auto issue_rows = [&](f32x4(&kr)[kU], int r0) {
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
         kr[u] = row_load<kRowsNT>(reinterpret_cast<const f32x4*>(tb + (int64_t)lst[r < nr ? r : nr1] * kD));
       }
     };
-    issue_rows(ka, 0);
-    issue_rows(kb, 4 * kU);
+#pragma unroll
+    for (int i = 0; i < kNA; ++i) issue_rows(kbuf[i], 4 * kU * i);
     // ---- last position: x -> q = x Wq + bq -> q_back = Wk q ---------------------------------------------------
     x_last = last_ok ? x_last : 0.f;
     xbuf[lane] = x_last;
@@ -281,11 +293,12 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
       }
       m = mb;
     };
-    for (int r0 = 0; r0 < nr; r0 += 8 * kU) {
-      reduce_rows(ka, r0);
-      issue_rows(ka, r0 + 8 * kU);
-      if (r0 + 4 * kU < nr) reduce_rows(kb, r0 + 4 * kU);
-      issue_rows(kb, r0 + 12 * kU);
+    for (int r0 = 0; r0 < nr; r0 += 4 * kU * kNA) {
+#pragma unroll
+      for (int i = 0; i < kNA; ++i) {
+        if (i == 0 || r0 + 4 * kU * i < nr) reduce_rows(kbuf[i], r0 + 4 * kU * i);
+        issue_rows(kbuf[i], r0 + 4 * kU * (i + kNA));
+      }
     }
     // ---- candidate batches 0 and 1 leave now; they land while the Wv / LN / FFN chain runs -------------------
     const float* pos_t = n_pos > 0 ? pos_table : neg_table;     // slots past the end read row 0 of an existing table
@@ -305,8 +318,8 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
         kr[u] = row_load<kRowsNT>(reinterpret_cast<const f32x4*>(tp + (int64_t)(id >= 0 ? id : 0) * kD));
       }
     };
-    issue_cand(ka, 0);
-    issue_cand(kb, 4 * kU);
+    issue_cand(kbuf[0], 0);
+    issue_cand(kbuf[1], 4 * kU);
     // merge the four group states
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
@@ -373,11 +386,14 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
         logits[b * logits_stride + jw] = ok ? mine : 0.f;      // out-of-range candidate: zero row
       }
     };
-    for (int jb = 0; jb < n_cand; jb += 8 * kU) {
-      reduce_cand(ka, jb);
-      issue_cand(ka, jb + 8 * kU);
-      if (jb + 4 * kU < n_cand) reduce_cand(kb, jb + 4 * kU);
-      issue_cand(kb, jb + 12 * kU);
+#pragma unroll
+    for (int i = 2; i < kNC; ++i) issue_cand(kbuf[i], 4 * kU * i);   // the matvec chain's registers are free now
+    for (int jb = 0; jb < n_cand; jb += 4 * kU * kNC) {
+#pragma unroll
+      for (int i = 0; i < kNC; ++i) {
+        if (i == 0 || jb + 4 * kU * i < n_cand) reduce_cand(kbuf[i], jb + 4 * kU * i);
+        issue_cand(kbuf[i], jb + 4 * kU * (i + kNC));
+      }
     }
   }
 }
