@@ -235,6 +235,35 @@ __device__ __forceinline__ float act_ct(float v, int act) {
   else return act_apply(v, act, 0.f);
 }
 
+// Wave priority by phase (round 3).  A layer is a chain of matrix bursts (12-36 MFMAs) and VALU phases (activations,
+// softmax); three waves share a SIMD's matrix pipe and its vector issue port, arbitrated by priority, then age
+// (MI355X_MICROARCH.md § Two waves per SIMD).  With every wave at priority 0 the pipe was 0.57 busy: a wave that reaches a
+// matrix burst queues behind older waves' VALU.  2 (shipped) = matrix bursts at priority 3, VALU phases at 0: the wave that
+// has MFMAs to issue wins the port (an MFMA holds it for a few cycles of its 32), VALU fills the gaps.  Same-box A/B
+// (tools/exp/autoint_prio_ab.sh, profiles/r03_autoint_prio_ab*.txt): 0 = 77.3-77.8 us, 1 (VALU phases high) = 75.0-75.2,
+// 2 = 72.9-73.3; the s_setprio instructions also pin the phase boundaries for the scheduler (146 VGPRs, no spill,
+// instead of 168 + 6 spilled).
+#ifndef REC_AUTOINT_PRIO
+#define REC_AUTOINT_PRIO 2
+#endif
+#ifndef REC_AUTOINT_BATCHQT
+#define REC_AUTOINT_BATCHQT 0
+#endif
+__device__ __forceinline__ void prio_valu() {
+#if REC_AUTOINT_PRIO == 1
+  __builtin_amdgcn_s_setprio(3);
+#elif REC_AUTOINT_PRIO == 2
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+__device__ __forceinline__ void prio_mfma() {
+#if REC_AUTOINT_PRIO == 1
+  __builtin_amdgcn_s_setprio(0);
+#elif REC_AUTOINT_PRIO == 2
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 template <int NT, int KS, int H, int ACT>
 __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4* __restrict__ wl, bool has_res, int act,
                                           int N, int lr, int g, f32x4 (&xo)[NT][H]) {
@@ -254,12 +283,14 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       f32x4 a = zero, c = zero, d = zero;
+      prio_mfma();
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         a = mfma4(wq[ks], xf[rt][ks], a);   // Q^T: column = field, rows = dims 4g + r
         c = mfma4(wk[ks], xf[rt][ks], c);   // K^T
         d = mfma4(xf[rt][ks], wv[ks], d);   // V: column = dim, rows = fields 4g + r
       }
+      prio_valu();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         a[r] = act_ct<ACT>(a[r], act) * scale;   // scores are linear in Q: scale once here
@@ -268,13 +299,76 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
       }
       qf[rt] = a, kf[rt] = c, vf[rt] = d;
     }
+#if REC_AUTOINT_BATCHQT
+    // A/B: the three query tiles as ONE scores burst (NT x NT x 4 MFMAs), one softmax phase, one PV + residual burst —
+    // a third of the phase switches (MFMA <-> VALU hazard slots, priority flips) for 24 more registers
+    f32x4 scq[NT][NT];
+    float invq[NT];
+    prio_mfma();
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) scq[qt][kt] = mfma4(kf[kt], qf[qt], zero);
+    prio_valu();
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (kt == NT - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scq[qt][kt][r] = kt * 16 + 4 * g + r < N ? scq[qt][kt][r] : -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, scq[qt][kt][r]);
+      }
+      mloc = rows_max(mloc);
+      float lsum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(scq[qt][kt][r] - mloc);
+          scq[qt][kt][r] = p;
+          lsum += p;
+        }
+      invq[qt] = __builtin_amdgcn_rcpf(rows_sum(lsum));
+    }
+    f32x4 oq[NT], rq[NT];
+    prio_mfma();
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 o = zero, rr = zero;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) o = mfma4(vf[kt], scq[qt][kt], o);
+      if (has_res) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rr = mfma4(w0[ks], xf[qt][ks], rr);
+      }
+      oq[qt] = o, rq[qt] = rr;
+    }
+    prio_valu();
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 o = oq[qt] * invq[qt];
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = relu_nan(o[r] + act_ct<ACT>(rq[qt][r], act));
+      }
+      xo[qt][h] = o;
+    }
+#else
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       f32x4 sc[NT];
       float mloc = -INFINITY;
+      prio_mfma();
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) sc[kt] = mfma4(kf[kt], qf[qt], zero);
+      prio_valu();
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        sc[kt] = mfma4(kf[kt], qf[qt], zero);   // transposed scores (x sqrt(S) log2 e): column = query, rows = keys 4g + r
+        // sc: transposed scores (x sqrt(S) log2 e): column = query, rows = keys 4g + r
         if (kt == NT - 1) {                      // only the last key tile can hold padding keys
 #pragma unroll
           for (int r = 0; r < 4; ++r) sc[kt][r] = kt * 16 + 4 * g + r < N ? sc[kt][r] : -INFINITY;
@@ -295,18 +389,23 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
       lsum = rows_sum(lsum);
       const float inv = __builtin_amdgcn_rcpf(lsum);   // v_rcp_f32 (1 ulp; lsum in [1, N]) instead of the IEEE division sequence
       f32x4 o = zero;
+      prio_mfma();
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) o = mfma4(vf[kt], sc[kt], o);   // O^T = V^T P^T (unnormalised)
-      o *= inv;
+      f32x4 rr = zero;
       if (has_res) {
-        f32x4 rr = zero;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) rr = mfma4(w0[ks], xf[qt][ks], rr);
+      }
+      prio_valu();
+      o *= inv;
+      if (has_res) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = relu_nan(o[r] + act_ct<ACT>(rr[r], act));
       }
       xo[qt][h] = o;   // rows of padded fields (>= N) carry values nobody reads: keys >= N are masked, queries >= N unused
     }
+#endif
   }
 }
 
@@ -327,7 +426,8 @@ __device__ __forceinline__ void stage_weights(f32x4* __restrict__ wl, const floa
 
 // workgroups per CU the register budget is cut for (tools/exp/autoint_wg_ab.sh, configs[2], same box): unconstrained 196 VGPRs
 // (two waves per SIMD) 83.6 us; 2 -> 176 VGPRs 80.8 us; 3 -> 168 VGPRs + 2 spilled, three waves per SIMD, 76.6 us (shipped):
-// a third wave per SIMD overlaps one sample's softmax VALU with another's matrix work
+// a third wave per SIMD overlaps one sample's softmax VALU with another's matrix work.  Round 3, with the phase priorities:
+// 2 / 3 / 4 workgroups per CU = 76.2 / 73.3 / 79.5 us (4 spills 23 registers)
 #ifndef REC_AUTOINT_MINWG
 #define REC_AUTOINT_MINWG 3
 #endif
@@ -380,8 +480,9 @@ __global__ __launch_bounds__(256, (NT <= 3 && KS0 == 1) ? REC_AUTOINT_MINWG : 2)
   };
   // persistent over samples: b = wave + k * waves (weights are staged once per workgroup).  (Round 3 A/B: requesting the
   // NEXT sample's rows before this sample's layers costs 12 more registers under the 168 cap — 14 spilled instead of 2 —
-  // and runs 80.2 us against 76.8; starting the workgroups of a CU 2-16 k cycles apart: 80.6-83.5 us.  Neither the
-  // input latency nor phase lockstep is what the kernel waits for: profiles/r03_autoint_ab.txt.)
+  // and runs 80.2 us against 76.8 (with the phase priorities below and no spill: 73.7 vs 73.3, still nothing); starting
+  // the workgroups of a CU 2-16 k cycles apart: 80.6-83.5 us.  Neither the input latency nor phase lockstep is what the
+  // kernel waits for: profiles/r03_autoint_ab.txt, r03_autoint_prio_ab2.txt.)
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t b = (int64_t)blockIdx.x * 4 + (tid >> 6); b < B; b += nwaves) {
     f32x4 x0[NT][KS0];

@@ -139,82 +139,9 @@ __global__ __launch_bounds__(256, 4) void gather_uniform_kernel(
   }
 }
 
-// Round 3 variant (rec_debug_force("gather", "p") until measured ahead): PERSISTENT waves walk the 64-row chunks with a
-// grid stride, and the ids of a wave's NEXT chunk are requested before the current chunk's rows move — the id -> row
-// dependency (two HBM round trips per chunk in the kernel above) is off the critical path and no wave ramps up twice.
-template <int LPR, int IDS_F32>
-__global__ __launch_bounds__(256, 4) void gather_uniform_persist_kernel(
-    TableSet ts, const void* __restrict__ ids, int64_t ids_stride, int F, int64_t R,
-    float* __restrict__ out, int64_t out_stride, int* __restrict__ oob) {
-  constexpr int D = LPR * 4;
-  constexpr int RPI = 64 / LPR;
-  constexpr int NIT = LPR;
-  constexpr int U = NIT < 16 ? NIT : 16;
-  const int lane = threadIdx.x & 63;
-  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nchunks = (R + 63) / 64;
-  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
-  int64_t chunk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-  const int sub = lane / LPR;
-  const int col = (lane % LPR) * 4;
-  // (b, f) of this lane's row of a chunk (f = -1 past the end); recomputed where needed: only the prefetched id is
-  // carried across the loop (the register budget of four blocks per CU is exactly met by the landing + address arrays)
-  auto locate = [&](int64_t ch, int64_t& b, int& f) {
-    const int64_t r = ch * 64 + lane;
-    f = -1;
-    b = 0;
-    if (ch < nchunks && r < R) {
-      const uint32_t b32 = (uint32_t)((uint64_t)r / (uint32_t)F);
-      b = b32;
-      f = (int)(r - (int64_t)b32 * F);
-    }
-  };
-  auto fetch = [&](int64_t ch) -> int32_t {
-    int64_t b;
-    int f;
-    locate(ch, b, f);
-    return f >= 0 ? load_id<IDS_F32>(ids, b * ids_stride + f) : 0;
-  };
-  int32_t id_n = fetch(chunk);
-  for (; chunk < nchunks; chunk += stride) {
-    const int32_t id = id_n;
-    id_n = fetch(chunk + stride);   // lands while this chunk's rows move
-    int64_t b;
-    int f;
-    locate(chunk, b, f);
-    uint64_t src = reinterpret_cast<uint64_t>(ts.base[0]) | 1u;
-    uint32_t dst = 0xffffffffu;   // destination as a 16-B offset from `out` (host checks that it fits): 16 registers
-    if (f >= 0) {                 // less than 64-bit addresses for the 16 rows in flight
-      dst = (uint32_t)((uint64_t)(b * out_stride + ts.out_col[f]) >> 2);
-      if ((uint32_t)id < (uint32_t)ts.vocab[f]) src = reinterpret_cast<uint64_t>(ts.base[f] + (int64_t)id * D);
-      else if (oob) *oob = 1;
-    }
-    const bool full = (chunk + 1) * 64 <= R;  // wave-uniform
-#pragma unroll 1
-    for (int it0 = 0; it0 < NIT; it0 += U) {
-      u32x4 v[U];
-      uint32_t d[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = (it0 + u) * RPI + sub;
-        const uint64_t s = shfl_u64(src, j);
-        d[u] = __shfl(dst, j, 64);
-        u32x4 t = *reinterpret_cast<gsrc_t>((s & ~(uint64_t)1) + col * 4);
-        const uint32_t keep = (uint32_t)(s & 1) - 1u;
-        v[u] = t & keep;
-      }
-      const uint64_t obase = reinterpret_cast<uint64_t>(out) + (uint64_t)col * 4;
-      if (full) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) row_store(v[u], obase + ((uint64_t)d[u] << 4));
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (d[u] != 0xffffffffu) row_store(v[u], obase + ((uint64_t)d[u] << 4));
-      }
-    }
-  }
-}
+// Round 3 A/B (profiles/r03_gather_persist_ab.txt): a variant with PERSISTENT waves and the ids of a wave's next 64-row
+// chunk prefetched before the current chunk's rows move measured 307-328 us against 307-317 us for this kernel on the same
+// box (uniform ids; Zipf: 256-261 vs 248-263): the id -> row dependency is not what bounds it.  Not kept.
 
 // Generic path: any per-field dim / alignment.  One wave per (b,f) row group; dword copies.
 template <int IDS_F32>
@@ -271,25 +198,10 @@ static int launch_gather(const TableSet& ts, int lpr, bool fast, const void* ids
   const int64_t chunks = (R + 63) / 64;
   const int64_t blocks = (chunks + 3) / 4;
   REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "rec_gather_concat_f32: batch too large");
-  const char* fg = forced("gather");
-  const bool persist = fg && fg[0] == 'p' && R < 0x7fffffffLL * 32 && (uint64_t)((R + F - 1) / F) * (uint64_t)out_stride < (0xffffffffULL << 2);
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    (void)hipGetDevice(&dev);
-    (void)hipGetDeviceProperties(&prop, dev);
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  const int64_t pblocks = blocks < (int64_t)cus * 4 ? blocks : (int64_t)cus * 4;   // 4 resident blocks per CU
 #define REC_LAUNCH_LPR(L)                                                                    \
   case L:                                                                                    \
-    if (persist)                                                                             \
-      hipLaunchKernelGGL((gather_uniform_persist_kernel<L, IDS_F32>), dim3((unsigned)pblocks), dim3(256), 0, st, ts, ids, \
-                         ids_stride, F, R, out, out_stride, oob);                            \
-    else                                                                                     \
-      hipLaunchKernelGGL((gather_uniform_kernel<L, IDS_F32>), dim3((unsigned)blocks), dim3(256), \
-                         0, st, ts, ids, ids_stride, F, R, out, out_stride, oob);            \
+    hipLaunchKernelGGL((gather_uniform_kernel<L, IDS_F32>), dim3((unsigned)blocks), dim3(256), \
+                       0, st, ts, ids, ids_stride, F, R, out, out_stride, oob);              \
     break;
   if (fast) {
     switch (lpr) {

@@ -165,22 +165,3 @@ def test_place_table_arena_reports_every_candidate(dev):
     both, info3 = ops.place_table_arena(F, V, D, dev, candidates=2, probe=[probe, probe], probe_launches=2)   # several kernels
     assert tuple(both.shape) == (F, V, D) and len(info3["probe_us"]) == 2 and all(len(t) == 2 for t in info3["probe_us"])
 
-
-@pytest.mark.parametrize("B,F,D", [(1, 3, 128), (700, 26, 128), (4097, 5, 64), (33, 64, 16), (20000, 26, 128)])
-def test_persistent_variant_is_bit_identical(dev, force, B, F, D):
-    """the persistent-waves gather with prefetched ids (forced: "gather" "p") writes exactly what the default kernel
-    writes — out-of-range ids, wide output rows with a column offset, and the flag included"""
-    from recamd import ops
-    rng = np.random.default_rng(B + F + D)
-    V = 300
-    tables = [torch.from_numpy(rng.normal(size=(V + f, D)).astype(np.float32)).to(dev) for f in range(F)]
-    ids = np.stack([rng.integers(-1, V + f + 1, size=B) for f in range(F)], axis=1).astype(np.int32)
-    t_ids = torch.from_numpy(ids).to(dev)
-    g = ops.TableGroup(tables, out_cols=[4 + f * D for f in range(F)])
-    a, fa = torch.full((B, F * D + 8), 7.0, device=dev), ops.new_oob_flag(dev)
-    ops.gather_concat(g, t_ids, out=a, oob_flag=fa)
-    force("gather", "p")
-    b, fb = torch.full((B, F * D + 8), 7.0, device=dev), ops.new_oob_flag(dev)
-    ops.gather_concat(g, t_ids, out=b, oob_flag=fb)
-    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and int(fa.item()) == int(fb.item())
-    assert bool((b[:, :4] == 7.0).all()) and bool((b[:, 4 + F * D:] == 7.0).all())       # nothing outside the concat columns
