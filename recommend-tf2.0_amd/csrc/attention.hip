@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, (NTAB * LPR <= 48 ? 4 : 1)) void din_gather_po
   constexpr float kLog2e = 1.4426950408889634f;
   extern __shared__ int32_t din_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;   // 4 waves per block, or 1 (see the dispatch)
   if (b >= B) return;
   int32_t* sid = din_lds + (size_t)w * T * (NTAB + 1);   // [T][NTAB] ids of the sample
   int32_t* slots = sid + (size_t)T * NTAB;                // [<= T] slots to fetch, in order; bit 31 = padded slot
@@ -858,8 +858,13 @@ extern "C" int rec_gather_din_attn_pool_f32(const float* q, const rec_table_desc
   // rows of 16 / 32 / 64 / 128 floats (4 / 8 / 16 / 32 lanes x 16 B): one lane group per history slot
   // (din_gather_pool_grp_kernel; 64 is the BASELINE configs[3] width).  Register budget: NTAB x LPR <= 64 (d <= 256)
   if (grp_ok && (Dt == 64 || Dt == 32 || Dt == 16 || Dt == 128) && n_tab <= 4 && n_tab * Dt <= 256 && lds <= 48 * 1024) {
+    // ONE wave per workgroup (round 3): a sample's wave slot is free again as soon as that sample is done, instead of when
+    // the workgroup's four histories are (history lengths differ up to 100 x) — 65.4 -> 64.4 us at configs[3], same box,
+    // three interleaved repeats (profiles/r03_din_wpb_ab.txt)
+    const dim3 ggrid((unsigned)B), gblock(64);
+    const size_t glds = lds / 4;
 #define REC_DIN_GRP(IDF_, NT_, LPR_)                                                                                      \
-  hipLaunchKernelGGL((din_gather_pool_grp_kernel<IDF_, NT_, LPR_>), grid, block, lds, st, q, tb, ids, mask, mode, W, bias, \
+  hipLaunchKernelGGL((din_gather_pool_grp_kernel<IDF_, NT_, LPR_>), ggrid, gblock, glds, st, q, tb, ids, mask, mode, W, bias, \
                      alpha, act, B, T, out, oob_flag)
 #define REC_DIN_GRP_NT(IDF_, LPR_)             \
   if (n_tab == 1) REC_DIN_GRP(IDF_, 1, LPR_);  \

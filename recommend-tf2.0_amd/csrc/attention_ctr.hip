@@ -246,9 +246,7 @@ __device__ __forceinline__ float act_ct(float v, int act) {
 #ifndef REC_AUTOINT_PRIO
 #define REC_AUTOINT_PRIO 2
 #endif
-#ifndef REC_AUTOINT_BATCHQT
-#define REC_AUTOINT_BATCHQT 0
-#endif
+
 __device__ __forceinline__ void prio_valu() {
 #if REC_AUTOINT_PRIO == 1
   __builtin_amdgcn_s_setprio(3);
@@ -299,65 +297,8 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
       }
       qf[rt] = a, kf[rt] = c, vf[rt] = d;
     }
-#if REC_AUTOINT_BATCHQT
-    // A/B: the three query tiles as ONE scores burst (NT x NT x 4 MFMAs), one softmax phase, one PV + residual burst —
-    // a third of the phase switches (MFMA <-> VALU hazard slots, priority flips) for 24 more registers
-    f32x4 scq[NT][NT];
-    float invq[NT];
-    prio_mfma();
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) scq[qt][kt] = mfma4(kf[kt], qf[qt], zero);
-    prio_valu();
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      float mloc = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        if (kt == NT - 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) scq[qt][kt][r] = kt * 16 + 4 * g + r < N ? scq[qt][kt][r] : -INFINITY;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, scq[qt][kt][r]);
-      }
-      mloc = rows_max(mloc);
-      float lsum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(scq[qt][kt][r] - mloc);
-          scq[qt][kt][r] = p;
-          lsum += p;
-        }
-      invq[qt] = __builtin_amdgcn_rcpf(rows_sum(lsum));
-    }
-    f32x4 oq[NT], rq[NT];
-    prio_mfma();
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      f32x4 o = zero, rr = zero;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) o = mfma4(vf[kt], scq[qt][kt], o);
-      if (has_res) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) rr = mfma4(w0[ks], xf[qt][ks], rr);
-      }
-      oq[qt] = o, rq[qt] = rr;
-    }
-    prio_valu();
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      f32x4 o = oq[qt] * invq[qt];
-      if (has_res) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = relu_nan(o[r] + act_ct<ACT>(rq[qt][r], act));
-      }
-      xo[qt][h] = o;
-    }
-#else
+    // (round 3 A/B: the three query tiles as ONE scores burst / one softmax phase / one PV burst — a third of the phase
+    // switches for 11 more registers — 73.2-73.5 us either way, profiles/r03_autoint_prio_ab3.txt; not kept)
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       f32x4 sc[NT];
@@ -405,7 +346,6 @@ __device__ __forceinline__ void ctr_layer(const f32x4 (&xf)[NT][KS], const f32x4
       }
       xo[qt][h] = o;   // rows of padded fields (>= N) carry values nobody reads: keys >= N are masked, queries >= N unused
     }
-#endif
   }
 }
 

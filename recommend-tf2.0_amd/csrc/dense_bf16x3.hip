@@ -20,9 +20,6 @@
 #include "bf16x3.h"
 #include "common.h"
 
-#ifndef REC_DENSE_PRIO
-#define REC_DENSE_PRIO 0
-#endif
 namespace rec {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -186,11 +183,8 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
         a[t][p] = __builtin_bit_cast(bf16x8, frag[st][0][p][half][wm * 64 + t * 32 + l32]);
         b[t][p] = __builtin_bit_cast(bf16x8, frag[st][1][p][half][wn * 64 + t * 32 + l32]);
       }
-    // A/B (tools/exp/dense_prio_ab.sh): the matrix cluster at wave priority REC_DENSE_PRIO (cdna guide T5) — the
-    // co-resident workgroups' split / LDS-write VALU then yields the vector issue port to a wave with MFMAs to issue
-#if REC_DENSE_PRIO
-    __builtin_amdgcn_s_setprio(REC_DENSE_PRIO);
-#endif
+    // (round 3 A/B, profiles/r03_dense_prio_ab.txt: this cluster at wave priority 1 or 3 — the T5 recipe of the cdna
+    // guide, which helps the AutoInt stack — costs 7-11 % here: 0.362 -> 0.401 ms at 65 536 x 1024 x 512; not kept)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -204,9 +198,6 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // m m
         acc[i][j] = c;
       }
-#if REC_DENSE_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
   // iteration ks: set ks % PD (step ks, already in LDS) is refilled with step ks + PD; the MFMAs of step ks run; step
   // ks + 1 (loaded PD - 1 iterations ago into set (ks + 1) % PD) is split and written to the other LDS stage
@@ -376,11 +367,8 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
         a[t][p] = __builtin_bit_cast(bf16x8, frag[st][0][p][half][wm * 64 + t * 32 + l32]);
         b[t][p] = __builtin_bit_cast(bf16x8, frag[st][1][p][half][wn * 64 + t * 32 + l32]);
       }
-    // A/B (tools/exp/dense_prio_ab.sh): the matrix cluster at wave priority REC_DENSE_PRIO (cdna guide T5) — the
-    // co-resident workgroups' split / LDS-write VALU then yields the vector issue port to a wave with MFMAs to issue
-#if REC_DENSE_PRIO
-    __builtin_amdgcn_s_setprio(REC_DENSE_PRIO);
-#endif
+    // (round 3 A/B, profiles/r03_dense_prio_ab.txt: this cluster at wave priority 1 or 3 — the T5 recipe of the cdna
+    // guide, which helps the AutoInt stack — costs 7-11 % here: 0.362 -> 0.401 ms at 65 536 x 1024 x 512; not kept)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -394,9 +382,6 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // m m
         acc[i][j] = c;
       }
-#if REC_DENSE_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
   const int nk = K / BK;   // even, >= 2
   uint32_t tok;
