@@ -65,21 +65,15 @@ constexpr int kU = REC_SASREC_KU;   // row-load instructions per landing buffer 
 #endif
 constexpr int kNA = REC_SASREC_ATT_BUFS, kNC = REC_SASREC_CAND_BUFS;
 // Experiment builds only (-DREC_SASREC_STAMPS, tools/exp/sasrec_stamps.py): s_memtime at the phase boundaries of every
-// sample, written over seq_info[b, 0..8] (lane 0) — where a sample's ~20 us go (profiles/r03_sasrec_stamps.txt: attention
-// loop 29 %, matvec chain 27 %, candidate loop 28 %, id compaction 9 %, Wq / Wk 6 %; weight staging 3.2 us per workgroup).
+// sample, written over seq_info[b, 0..7] (lane 0) — where a sample's ~20 us go.
 #ifdef REC_SASREC_STAMPS
 #define REC_STAMP(i) do { if (lane == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define REC_STAMP(i) do { } while (0)
 #endif
-// Round 3 also tried DYNAMIC sample -> wave assignment (ticket counters, tools/exp/sasrec_variants/sasrec_fused_tickets.hip):
-// bit-identical results, but 86.0-86.2 us against 84.5-85.3 us for this static stride on the same box, whether a wave
-// claims its next sample at the top of the current one or as late as its ids can still arrive
-// (profiles/r03_sasrec_balanced_ab_*.txt) — and device-scope atomics on ONE address serialise at ~27 ns (a single
-// counter plus a "last wave out" counter: 371 / 273 us).  The waves' busy times differ (mean 46, max 63 of the same
-// units), yet evening them out buys nothing: what bounds the kernel is the rate at which the memory system serves 256-B
-// row requests to all waves together, not the slowest wave.
 constexpr int kNB = kNA > kNC ? kNA : kNC;
+constexpr int kTicketGroups = 32, kTicketStride = 64;   // ticket counters (int32), 256 B apart; two sets
+static_assert(2 * kTicketGroups * kTicketStride == REC_SASREC_TICKET_INTS, "recamd.h");
 
 struct SasrecParams {
   const float *wq, *bq, *wk, *wv, *bv, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
@@ -160,7 +154,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     const float* __restrict__ pos_table, int32_t pos_vocab, const int32_t* __restrict__ pos_ids, int64_t pos_stride,
     int n_pos, const float* __restrict__ neg_table, int32_t neg_vocab, const int32_t* __restrict__ neg_ids,
     int64_t neg_stride, int n_neg, int64_t B, float* __restrict__ seq_info, float* __restrict__ logits,
-    int64_t logits_stride, int* __restrict__ oob, int lst_cap, int cand_cap) {
+    int64_t logits_stride, int* __restrict__ oob, int lst_cap, int cand_cap, int* __restrict__ tickets_all, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef REC_SASREC_STAMPS
   const long long t_entry = (long long)__builtin_amdgcn_s_memtime();
@@ -194,6 +188,24 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     if (lane_c == 0) glds4(mask_ids + bb * mask_stride, lds0 + (uint32_t)(2 * lst_cap + cand_cap + which) * 4u);
   };
   if (b < B) prefetch_seq_ids(b, 0);
+  // Sample -> wave assignment (round 3).  A wave's first sample is static; every further one is a ticket: history
+  // lengths differ up to 200 x, and with a static stride a wave that drew two long samples set the kernel's time —
+  // per-wave busy time mean 45 us, max 63 us of an 85-us kernel (tools/exp/sasrec_stamps.py,
+  // profiles/r03_sasrec_stamps.txt).  kTicketGroups counters, 256 B apart (device-scope atomics on ONE address
+  // serialise at ~27 ns each: 12 k of them on a single counter made the kernel 371 us): workgroup x draws from counter
+  // x % kTicketGroups, whose pool is the samples b >= nwaves with (b - nwaves) % kTicketGroups == its index.  The ticket
+  // for the next sample is requested after a sample's attention loop and read after its matvec chain (the atomic's
+  // latency is never waited for); tickets == NULL keeps the static stride.
+  // No counter is ever reset by a launch that uses it (a "last wave out" counter would be 4 096 more serialised atomics on
+  // one address — that alone ran the kernel at 273 us): the buffer holds TWO sets, launch k draws from set k & 1 and
+  // zeroes the other one, which launch k - 1 used and launch k + 1 will use (launches on one stream are serialised; the
+  // caller flips `parity` per launch).
+  const int64_t nwaves_all = bstep;
+  const int tgroup = (int)(blockIdx.x % kTicketGroups);
+  int* const tickets = tickets_all ? tickets_all + (parity & 1) * kTicketGroups * kTicketStride : nullptr;
+  if (tickets_all && blockIdx.x == 0 && tid < kTicketGroups)
+    tickets_all[((parity & 1) ^ 1) * kTicketGroups * kTicketStride + tid * kTicketStride] = 0;
+  int tk = 0;
   auto w4 = [](int i, int c, int ncol) { return ((i >> 2) * ncol + c) * 4 + (i & 3); };
   for (int e = tid; e < 64 * 64; e += kWaves * 64) {       // e = i * 64 + o of the Keras (in, out) kernels
     const int i = e >> 6, o = e & 63;
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
   // before the Wq / Wk matvecs; row batch i + 2 as soon as batch i has been reduced (two landing buffers in
   // registers); the first two candidate batches before the Wv / LN / FFN chain (candidate rows do not depend on it).
   int cur = 0;
-  for (; b < B; b += bstep, cur ^= 1) {
+  for (; b < B; cur ^= 1) {
     // everything lane-dependent below derives from a laundered lane index: otherwise the compiler hoists dozens of
     // per-lane invariants (bias reads, table-select pointers of every unrolled slot) out of this loop and spills them
     int ln = lane_c;
@@ -245,7 +257,6 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
         glds4(j < n_pos ? pos_ids + b * pos_stride + j : neg_ids + b * neg_stride + (j - n_pos),
               lds0 + (uint32_t)(2 * lst_cap + c * 64) * 4u);
     }
-    if (b + bstep < B) prefetch_seq_ids(b + bstep, cur ^ 1);
     // ---- list of the slots that hold a real row, compacted in place; everything else is a zero row --------------
     const int32_t id_last = lst[S - 1];
     const float mask_last = msk[cur] != 0 ? 1.f : 0.f;
@@ -326,6 +337,12 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
       }
     }
     REC_STAMP(4);   // attention rows reduced
+    // the next sample is claimed as LATE as its ids can still arrive in time: requested here, read after the matvec chain,
+    // its ids land during the candidate loop.  (Claimed at the top of a sample, every wave reserves its second sample
+    // at t = 0 — with two samples per wave that is the static stride again: 86.2 vs 85.2 us,
+    // profiles/r03_sasrec_balanced_ab_early_claim.txt.)
+    if (tickets && lane_c == 0)
+      tk = __hip_atomic_fetch_add(tickets + tgroup * kTicketStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- candidate batches 0 and 1 leave now; they land while the Wv / LN / FFN chain runs -------------------
     const float* pos_t = n_pos > 0 ? pos_table : neg_table;     // slots past the end read row 0 of an existing table
     const float* neg_t = n_neg > 0 ? neg_table : pos_table;
@@ -390,6 +407,9 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
     const float si = layer_norm64(out1 + f, vec[320 + lane], vec[384 + lane], P.eps2) * mask_last;
     if (seq_info) seq_info[b * kD + lane] = si;
     REC_STAMP(5);   // Wv, LN1, FFN, LN2 done
+    const int64_t b_next = tickets ? nwaves_all + (int64_t)__builtin_amdgcn_readfirstlane(tk) * kTicketGroups + tgroup
+                                   : b + bstep;
+    if (b_next < B) prefetch_seq_ids(b_next, cur ^ 1);   // lands during the candidate loop
     // ---- candidates: logits[b, j] = table_j[id_j] . seq_info ----------------------------------------------------
     xbuf[lane] = si;
     wave_lds_sync();
@@ -422,14 +442,18 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
         issue_cand(kbuf[i], jb + 4 * kU * (i + kNC));
       }
     }
+    const int64_t b_done = b;
+    (void)b_done;
+    b = b_next;
 #ifdef REC_SASREC_STAMPS
     if (lane == 0) {
       stamps[6] = (long long)__builtin_amdgcn_s_memtime();
       if (seq_info) {
-        for (int i = 1; i <= 6; ++i) seq_info[b * kD + i - 1] = (float)(stamps[i] - stamps[i - 1]);
-        seq_info[b * kD + 6] = (float)nr;
-        seq_info[b * kD + 7] = (float)(stamps[0] & 0xffffff);
-        seq_info[b * kD + 8] = (float)(stamps[0] - t_entry);     // kernel entry -> this sample's start
+        for (int i = 1; i <= 6; ++i) seq_info[b_done * kD + i - 1] = (float)(stamps[i] - stamps[i - 1]);
+        seq_info[b_done * kD + 6] = (float)nr;
+        seq_info[b_done * kD + 7] = (float)(stamps[0] & 0xffffff);
+        seq_info[b_done * kD + 8] = (float)(stamps[0] - t_entry);
+        seq_info[b_done * kD + 9] = (float)(blockIdx.x * kWaves + wave);     // kernel entry -> this sample's start
       }
     }
 #endif
@@ -454,13 +478,14 @@ extern "C" int rec_sasrec_last_row_supported(int32_t d, int32_t ffn_hidden, int3
   return lds <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
+extern "C" int rec_sasrec_last_row_balanced_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
                                        const int32_t* seq_ids, int64_t seq_ids_stride, int32_t S, int32_t pad_id,
                                        const int32_t* mask_ids, int64_t mask_stride, const float* pos_table,
                                        int32_t pos_vocab, const int32_t* pos_ids, int64_t pos_ids_stride, int32_t n_pos,
                                        const float* neg_table, int32_t neg_vocab, const int32_t* neg_ids,
                                        int64_t neg_ids_stride, int32_t n_neg, int64_t B, int32_t d, float* seq_info,
-                                       float* logits, int64_t logits_stride, int32_t* oob_flag, void* stream) {
+                                       float* logits, int64_t logits_stride, int32_t* oob_flag, int32_t* tickets,
+                                       int32_t parity, void* stream) {
   REC_CHECK_ARG(blk && seq_table && seq_ids && mask_ids && logits, REC_EINVAL, "sasrec_last_row: NULL argument");
   REC_CHECK_ARG(blk->wq && blk->bq && blk->wk && blk->wv && blk->bv && blk->ln1_gamma && blk->ln1_beta && blk->w1 &&
                     blk->b1 && blk->w2 && blk->b2 && blk->ln2_gamma && blk->ln2_beta,
@@ -510,7 +535,7 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds, st, P, seq_table, seq_vocab, seq_ids, seq_ids_stride,
                        (int)S, pad_id, mask_ids, mask_stride, pos_table, pos_vocab, pos_ids, pos_ids_stride, (int)n_pos,
                        neg_table, neg_vocab, neg_ids, neg_ids_stride, (int)n_neg, B, seq_info, logits, logits_stride,
-                       reinterpret_cast<int*>(oob_flag), lst_cap, cand_cap);
+                       reinterpret_cast<int*>(oob_flag), lst_cap, cand_cap, reinterpret_cast<int*>(tickets), (int)parity);
     return REC_OK;
   };
   int rc = blk->ffn_hidden == 128 ? launch(sasrec_last_row_kernel<128>, lds_bytes<128>(lst_cap, cand_cap))
@@ -518,4 +543,17 @@ extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float*
   if (rc != REC_OK) return rc;
   REC_CHECK_LAUNCH("sasrec_last_row");
   return REC_OK;
+}
+
+extern "C" int rec_sasrec_last_row_f32(const rec_sasrec_block* blk, const float* seq_table, int32_t seq_vocab,
+                                       const int32_t* seq_ids, int64_t seq_ids_stride, int32_t S, int32_t pad_id,
+                                       const int32_t* mask_ids, int64_t mask_stride, const float* pos_table,
+                                       int32_t pos_vocab, const int32_t* pos_ids, int64_t pos_ids_stride, int32_t n_pos,
+                                       const float* neg_table, int32_t neg_vocab, const int32_t* neg_ids,
+                                       int64_t neg_ids_stride, int32_t n_neg, int64_t B, int32_t d, float* seq_info,
+                                       float* logits, int64_t logits_stride, int32_t* oob_flag, void* stream) {
+  return rec_sasrec_last_row_balanced_f32(blk, seq_table, seq_vocab, seq_ids, seq_ids_stride, S, pad_id, mask_ids, mask_stride,
+                                          pos_table, pos_vocab, pos_ids, pos_ids_stride, n_pos, neg_table, neg_vocab, neg_ids,
+                                          neg_ids_stride, n_neg, B, d, seq_info, logits, logits_stride, oob_flag, nullptr, 0,
+                                          stream);
 }
