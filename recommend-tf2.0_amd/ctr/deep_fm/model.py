@@ -34,7 +34,10 @@ class DeepFM(Model):
         for feat in self.sparse_feature_columns:
             cols.append(c)
             c += feat['embed_dim']
-        self.width = (c + 3) // 4 * 4
+        # row stride rounded up so the DNN's first GEMM reads K % 32 == 0 (the hand-counted Dense kernel): at most 31
+        # zero columns behind the features, matched by zero rows in the folded kernel
+        self.width = (c + 31) // 32 * 32
+        self.tail = self.width - c
         self._group = ops.TableGroup([self.embed_layers['embed_%d' % i].table
                                       for i in range(len(self.sparse_feature_columns))], out_cols=cols)
         dims = set(self._group.dims)
@@ -50,6 +53,8 @@ class DeepFM(Model):
         buf = torch.empty((B, self.width), dtype=torch.float32, device=self.device)
         if self.pad:
             buf[:, :self.pad] = 0.0                                             # pad columns of the dense block
+        if self.tail:
+            buf[:, self.width - self.tail:] = 0.0                               # pad columns behind the features
         buf[:, self.pad:self.pad + self.nd] = dense_inputs                      # dense part of the concat
         embeds = buf[:, self.pad:self.pad + self.feature_length]               # :56
         sparse_embed = buf[:, self.pad + self.nd:self.pad + self.feature_length]
@@ -65,6 +70,6 @@ class DeepFM(Model):
         else:
             ops.gather_concat(self._group, sparse_inputs, out=buf)              # :53 (sparse part)
             fm_outputs = self.fm([embeds, sparse_embed])                       # :59
-        # the DNN reads the 16-B aligned view that includes the zeroed pad columns (zero rows in its folded kernel)
-        deep_outputs = self.dense(self.dnn(buf[:, :self.pad + self.feature_length], lead_pad=self.pad))  # :61-62
+        # the DNN reads the whole 16-B aligned buffer, zeroed pad columns included (zero rows in its folded kernel)
+        deep_outputs = self.dense(self.dnn(buf, lead_pad=self.pad, tail_pad=self.tail))                    # :61-62
         return ops.add_sigmoid(fm_outputs, deep_outputs)                       # :64

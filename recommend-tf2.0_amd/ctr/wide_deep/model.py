@@ -25,11 +25,24 @@ class DNN(nn.Layer):
         self.dnn_network = [self.track(f'dense_{i}', nn.Dense(units=unit, activation=activation))
                             for i, unit in enumerate(hidden_units)]
         self.dropout = nn.Dropout(dropout)
+        self._padded = None
 
-    def call(self, inputs, **kwargs):
+    def call(self, inputs, tail_pad=0, **kwargs):
+        """tail_pad > 0: `inputs` carries that many ZERO columns behind the features (a row stride rounded up so that
+        K % 32 == 0); the first layer's kernel gets as many zero rows, the product is unchanged."""
         x = inputs
-        for dnn in self.dnn_network:
-            x = dnn(x)
+        for i, dnn in enumerate(self.dnn_network):
+            if i == 0 and tail_pad:
+                if not dnn.built:
+                    dnn.build(x.shape[-1] - tail_pad)
+                key = (dnn._version, tail_pad)
+                if self._padded is None or self._padded[0] != key:
+                    W = dnn._w['kernel']
+                    z = torch.zeros((tail_pad, W.shape[1]), dtype=W.dtype, device=W.device)
+                    self._padded = (key, torch.cat([W, z], dim=0).contiguous())
+                x = dnn.apply(x, self._padded[1], dnn._w.get('bias'))
+            else:
+                x = dnn(x)
         return self.dropout(x)
 
 
@@ -56,11 +69,16 @@ class WideDeep(Model):
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
         # x = concat([sparse_embed, dense_inputs]) (:70): the gather writes straight into the concat buffer
         B, nd, We = dense_inputs.shape[0], dense_inputs.shape[1], self._group.width
-        # row stride padded to a multiple of 4 floats: 16-B aligned rows keep the gather and the first Dense on their
-        # vector paths (a tight 3341-float stride halves the gather rate)
-        x = torch.empty((B, (We + nd + 3) // 4 * 4), dtype=torch.float32, device=self.device)[:, :We + nd]
+        # row stride padded to a multiple of 32 floats: 16-B aligned rows keep the gather on its vector path (a tight
+        # 3341-float stride halves the gather rate) and K % 32 == 0 puts the first Dense on its hand-counted kernel;
+        # the pad columns are zero and meet zero rows of the folded kernel
+        wide = (We + nd + 31) // 32 * 32
+        tail = wide - (We + nd)
+        x = torch.empty((B, wide), dtype=torch.float32, device=self.device)
+        if tail:
+            x[:, We + nd:] = 0.0
         ops.gather_concat(self._group, sparse_inputs, out=x)               # :68-69
-        ops.copy_cols(dense_inputs, x[:, We:])                           # tf.concat part written at its column offset
+        ops.copy_cols(dense_inputs, x[:, We:We + nd])                    # tf.concat part written at its column offset
         wide_out = self.linear(dense_inputs)                               # :73
-        deep_out = self.final_dense(self.dnn_network(x))                   # :75-76
+        deep_out = self.final_dense(self.dnn_network(x, tail_pad=tail))    # :75-76
         return ops.axpby_act(wide_out, deep_out, 0.5, 0.5, 'sigmoid')      # :78
