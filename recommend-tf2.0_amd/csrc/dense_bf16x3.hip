@@ -19,6 +19,7 @@
 
 #include "bf16x3.h"
 #include "common.h"
+#include "ring_dma.h"
 
 namespace rec {
 
@@ -264,39 +265,69 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_kernel(const float* __res
     }
 }
 
-// ---- the same tile with hand-counted global loads (aligned x rows, prepared W, K % 32 == 0) -----------------------
+// ---- the same tile with hand-counted loads (aligned x rows, prepared W, K % 32 == 0) ---------------------------------
 // In the kernel above the compiler owns the s_waitcnt placement, and across the loop's control flow it gives up on the
 // issue order: the ISA has `s_waitcnt vmcnt(2) / (1) / (0)` in front of the LDS writes of the PREVIOUS step's W planes —
 // it also waits for the loads it has just issued for the next step, so every k-step pays a full L2 / HBM round trip
 // (0.6 - 2 us against 0.35 us of matrix work per step; measured: prefetch distances 1, 2, 3, 4 all within 7 %).  With a
 // straight-line body and plain loads it derives exact counts but sinks the loads next to their uses.  So the loop's
-// loads are inline asm in a fixed order — per thread and k-step [x lo][x hi][W h][W m][W l] — and the counts are static:
-// at the LDS write of step ks + 1 the five loads of step ks + 2 may all be in flight (vmcnt(8) for its x pieces: three
-// older W loads + five newer; vmcnt(5) for its W planes).  Two register sets, loop unrolled by two, the last pair
-// peeled (no loads, vmcnt(3) / (0)): nothing is in flight at the epilogue.
-// The wait asm returns a zero the consumers fold in (xor into the x values, add to the LDS index of the W planes): the
-// data dependency that keeps their instructions below the wait.  (A tied 128-bit "+v" operand would be the natural way;
-// this toolchain lowers it as if the four elements were equal — the first version split one value per 16-B piece.)
-__device__ __forceinline__ void gl16(u32x4& dst, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
-}
-#define REC_DWAIT_X(n, tok, a, b) \
-  asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b) : "memory")
-#define REC_DWAIT_W(n, tok, a, b, c) \
-  asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b), "v"(c) : "memory")
-
-// register budget for three workgroups per CU (168 VGPRs + 1 spilled; unconstrained: 172, one over the three-per-CU limit):
-// 65 536 x 1024 x 512 184 -> 189 TFLOP/s, 8192 x 4096 x 4096 205 -> 206.5 (tools/exp/dense_wg_ab.sh): the kernel is bound by
-// its LDS operand traffic, not by occupancy
+// loads are inline asm in a fixed order and the counts are static.
+// Round 2's version of this kernel moved both operands through registers ([x lo][x hi][W h][W m][W l] per thread and
+// k-step, two register sets; kept as text in tools/exp/dense_variants/).  Round 3 took it apart (65 536 x 1024 x 512,
+// profiles/r03_dense_ablate*.txt, r03_mfma_peak.txt, r03_dense_stamps*.txt):
+//   * the matrix pipe alone sustains 2.1 - 2.27 PFLOP/s of this MFMA whatever the occupancy — the clock falls to
+//     1.35 - 1.6 GHz as waves are added: a power limit, 350 - 378 TFLOP/s fp32-equivalent at six MFMAs per product, 0.19 ms
+//     for this layer; with this kernel's LDS traffic and barrier beside it 304 - 320;
+//   * without any global load 0.362 -> 0.294 ms, with loads that always hit the L1 0.328 ms, without the split arithmetic
+//     0.355 ms: the loads cost a fifth, half of it in the memory system.  A thread read 32 B of its x row per k-step and the
+//     other half of that 128-B line one k-step later, after the CU's three workgroups had pulled 60 KB through a 32-KB L1:
+//     every x line came from the L2 twice.
+// So here
+//   * x is loaded a ROUND (two k-steps = one 128-B line per row and k-half pair) at a time: four 16-B pieces per thread,
+//     all issued together, each line fetched once;
+//   * the W planes never visit registers: global_load_lds_dwordx4 drops the 64 fragments a wave used to load, wait for
+//     and ds_write straight into the LDS stage (24 VGPRs and three ds_write_b128 per thread and k-step fewer).  The DMA
+//     for step ks + 1 is issued right after the barrier that retires that stage's readers and must land by the barrier
+//     that ends step ks: one k-step (~2 us with three workgroups per CU) for an L2 hit;
+//   * addresses are a scalar base plus one 32-bit lane offset per operand: no 64-bit vector arithmetic in the loop.
+// 140 VGPRs, three workgroups per CU, bit-identical results: 0.362 -> 0.350 ms, 65 536 x 3456 x 128 0.347 -> 0.325,
+// 8192 x 4096 x 4096 200 -> 211 TFLOP/s (profiles/r03_dense_pipe2_ab.txt).  Not kept after A/Bs on the same box: a
+// different issue priority per resident wave slot (the workgroups of a CU do not run in lock-step; r03_dense_slotprio_ab.txt),
+// MFMAs ordered term by term over the four accumulators and the split's VALU work placed between them with
+// sched_group_barrier (r03_dense_pipe2_order_ab.txt): all within 1 %.
+// One register set suffices: a round's four pieces are requested at the start of its predecessor's second k-step (both of
+// the set's halves have been split by then), their first half is split at the end of that step, the second half one step
+// later.  Counts (issue order in the odd step: [x x4][W x3]): vmcnt(3) before the split — the x pieces are older than the
+// three W loads — and vmcnt(0) before every barrier (the DMA'd planes must be in LDS when the stage is released).
+// The wait asm returns a zero the consumers fold in (xor into the x values): the data dependency that keeps their
+// instructions below the wait.  (A tied 128-bit "+v" operand would be the natural way; this toolchain lowers it as if the
+// four elements were equal.)  The loads land asynchronously, so a register the compiler spilled between a load's issue and
+// its wait would be clobbered when the load lands: both kernels below compile without spills, keep it that way
+// (-Rpass-analysis=kernel-resource-usage).
 #ifndef REC_DENSE_PIPE_WG
 #define REC_DENSE_PIPE_WG 3
 #endif
+// Experiment builds only (-DREC_DENSE_STAMPS, tools/exp/dense_stamps.py): s_memtime at the phase boundaries of every k-step
+// (with scheduling barriers: the phases do not overlap as they do in the product build), summed per wave and written OVER
+// the first floats of the workgroup's output tile (row m0 + wave, columns n0 .. n0 + 6)
+#ifdef REC_DENSE_STAMPS
+#define REC_DSTAMP(i) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph[i] += t_ - t_last; t_last = t_; } while (0)
+#endif
+// loads with a scalar base and a 32-bit per-lane offset: no 64-bit address arithmetic in the loop, one VGPR per operand
+__device__ __forceinline__ void gl16s(u32x4& dst, uint32_t voff, const void* sbase, int imm) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory");
+}
+#define REC_DWAIT_X2(n, tok, a, b) \
+  asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b) : "memory")
+// the pieces' second pair is consumed one step after the wait that covered it: a token without a wait ties its readers
+// below that wait (volatile asm statements keep their order)
+#define REC_DTOKEN_X2(tok, a, b) asm volatile("v_mov_b32 %0, 0" : "=v"(tok) : "v"(a), "v"(b) : "memory")
 __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kernel(const float* __restrict__ x, int64_t x_stride,
-                                                                   const float* __restrict__ bias,
-                                                                   const float* __restrict__ alpha, int act, int64_t M,
-                                                                   int K, int N, float* __restrict__ out,
-                                                                   int64_t out_stride, int out_vec,
-                                                                   const u32x4* __restrict__ Wp, int Np, int xcd_map) {
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ alpha, int act, int64_t M,
+                                                                    int K, int N, float* __restrict__ out,
+                                                                    int64_t out_stride, int out_vec,
+                                                                    const u32x4* __restrict__ Wp, int Np, int xcd_map) {
   using namespace b3;
   __shared__ u32x4 frag[2][2][3][2][128];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -321,8 +352,13 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
   const int n0 = nt_ * BN;
   const int srow = tid & 127, skh = tid >> 7;
   const int64_t gm = m0 + srow;
-  const float* xrow = x + (gm < M ? gm : 0) * x_stride + 8 * skh;        // rows >= M read row 0; never stored
-  const u32x4* wcol = Wp + (int64_t)skh * 3 * Np + n0 + srow;            // + (ks * 2) * 3 * Np per k-step
+  // scalar bases (uniform: block index arithmetic) + per-lane byte offsets; rows >= M read row m0 (never stored)
+  const float* xbase = x + m0 * x_stride;
+  const uint32_t xoff = (uint32_t)(((gm < M ? srow : 0) * x_stride + 8 * skh) * 4);
+  const u32x4* wbase = Wp + n0;                                          // + (ks * 2) * 3 * Np per k-step
+  const uint32_t woff = (uint32_t)((skh * 3 * Np + srow) * 16);
+  // LDS byte address of this wave's 64 fragments of plane 0 in W stage 0 (stage: + 24 KiB, plane: + 4 KiB)
+  const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_addr(&frag[0][1][0][skh][srow & 64]));
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -332,31 +368,45 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  u32x4 xa[2][2], wq[2][3];
-  auto issue = [&](int ks, u32x4 (&xs)[2], u32x4 (&ws)[3]) {
-    const float* px = xrow + ks * BK;
-    const u32x4* pw = wcol + (int64_t)ks * 6 * Np;
-    gl16(xs[0], px);
-    gl16(xs[1], px + 4);
-    gl16(ws[0], pw);
-    gl16(ws[1], pw + Np);
-    gl16(ws[2], pw + 2 * Np);
+  u32x4 xa[4];        // one round of this thread's x pieces: [step of the round * 2 + piece]
+#ifdef REC_DENSE_STAMPS
+  uint32_t ph[6] = {0u, 0u, 0u, 0u, 0u, 0u};      // wave-uniform: scalar registers
+  uint32_t t_last = (uint32_t)__builtin_amdgcn_s_memtime();
+  const uint32_t t_entry = t_last;
+#define REC_DSTAMP2(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); REC_DSTAMP(i); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define REC_DSTAMP2(i) do { } while (0)
+#endif
+  auto issue_x = [&](int r) {
+    const float* px = xbase + r * 2 * BK;
+    gl16s(xa[0], xoff, px, 0);
+    gl16s(xa[1], xoff, px, 16);
+    gl16s(xa[2], xoff, px, BK * 4);
+    gl16s(xa[3], xoff, px, BK * 4 + 16);
   };
-  auto lwrite_x = [&](int st, const u32x4 (&xs)[2], uint32_t tok) {
+  auto issue_w = [&](int ks, int st) {
+    const u32x4* pw = wbase + (int64_t)ks * 6 * Np;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(woff), "s"(pw), "s"(pw + Np), "s"(pw + 2 * Np),
+          "s"(__builtin_amdgcn_readfirstlane(wlds + (uint32_t)st * (uint32_t)sizeof(frag[0])))
+        : "memory");
+  };
+  auto lwrite_x = [&](int st, const u32x4& lo, const u32x4& hi, uint32_t tok) {
     float av[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      av[j] = __builtin_bit_cast(float, xs[0][j] ^ tok), av[4 + j] = __builtin_bit_cast(float, xs[1][j] ^ tok);
+    for (int j = 0; j < 4; ++j) av[j] = __builtin_bit_cast(float, lo[j] ^ tok), av[4 + j] = __builtin_bit_cast(float, hi[j] ^ tok);
     u32x4 h, m, l;
     split8(av, h, m, l);
     frag[st][0][0][skh][srow] = h;
     frag[st][0][1][skh][srow] = m;
     frag[st][0][2][skh][srow] = l;
-  };
-  auto lwrite_w = [&](int st, const u32x4 (&ws)[3], uint32_t tok) {
-    frag[st][1][0][skh][srow + tok] = ws[0];
-    frag[st][1][1][skh][srow + tok] = ws[1];
-    frag[st][1][2][skh][srow + tok] = ws[2];
   };
   auto compute = [&](int st) {
     bf16x8 a[2][3], b[2][3];
@@ -367,8 +417,7 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
         a[t][p] = __builtin_bit_cast(bf16x8, frag[st][0][p][half][wm * 64 + t * 32 + l32]);
         b[t][p] = __builtin_bit_cast(bf16x8, frag[st][1][p][half][wn * 64 + t * 32 + l32]);
       }
-    // (round 3 A/B, profiles/r03_dense_prio_ab.txt: this cluster at wave priority 1 or 3 — the T5 recipe of the cdna
-    // guide, which helps the AutoInt stack — costs 7-11 % here: 0.362 -> 0.401 ms at 65 536 x 1024 x 512; not kept)
+    REC_DSTAMP2(0);   // barrier release -> operands in registers
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -383,36 +432,45 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
         acc[i][j] = c;
       }
   };
-  const int nk = K / BK;   // even, >= 2
   uint32_t tok;
-#define REC_STEP_WRITE(n_x, n_w, st, S)              \
-  REC_DWAIT_X(n_x, tok, xa[S][0], xa[S][1]);         \
-  lwrite_x(st, xa[S], tok);                          \
-  REC_DWAIT_W(n_w, tok, wq[S][0], wq[S][1], wq[S][2]); \
-  lwrite_w(st, wq[S], tok)
-  issue(0, xa[0], wq[0]);
-  issue(1, xa[1], wq[1]);
-  REC_STEP_WRITE(8, 5, 0, 0);
+  const int nr = K / (2 * BK);   // rounds, >= 1
+  issue_x(0);
+  issue_w(0, 0);
+  REC_DWAIT_X2(3, tok, xa[0], xa[1]);
+  lwrite_x(0, xa[0], xa[1], tok);
+  REC_VMCNT(0);
   __syncthreads();
-  for (int ks = 0; ks + 2 < nk; ks += 2) {
-    // step ks (stage 0, set 0 free again): refill set 0 with step ks + 2, write step ks + 1 from set 1 to stage 1
-    issue(ks + 2, xa[0], wq[0]);
+  for (int r = 0; r < nr; ++r) {
+    const bool next = r + 1 < nr;
+    // k-step 2r (stage 0): the W planes of step 2r + 1 fly into stage 1 while the second half of this round's x is split
+    issue_w(2 * r + 1, 1);
     compute(0);
-    REC_STEP_WRITE(8, 5, 1, 1);
+    REC_DSTAMP2(1);   // MFMA issue
+    REC_DTOKEN_X2(tok, xa[2], xa[3]);
+    lwrite_x(1, xa[2], xa[3], tok);
+    REC_DSTAMP2(3);   // split + LDS writes
+    REC_VMCNT(0);
+    REC_DSTAMP2(4);   // W planes landed
     __syncthreads();
-    // step ks + 1 (stage 1): refill set 1 with step ks + 3, write step ks + 2 from set 0 to stage 0
-    issue(ks + 3, xa[1], wq[1]);
+    REC_DSTAMP2(5);   // barrier
+    // k-step 2r + 1 (stage 1): the next round's x lines and the W planes of its first step are requested up front
+    if (next) {
+      issue_x(r + 1);
+      issue_w(2 * r + 2, 0);
+    }
     compute(1);
-    REC_STEP_WRITE(8, 5, 0, 0);
+    REC_DSTAMP2(1);
+    if (next) {
+      REC_DWAIT_X2(3, tok, xa[0], xa[1]);
+      REC_DSTAMP2(2);  // x pieces landed
+      lwrite_x(0, xa[0], xa[1], tok);
+        REC_DSTAMP2(3);
+      REC_VMCNT(0);
+      REC_DSTAMP2(4);
+    }
     __syncthreads();
+    REC_DSTAMP2(5);
   }
-  // last pair: nothing left to load
-  compute(0);
-  REC_STEP_WRITE(3, 0, 1, 1);
-  __syncthreads();
-  compute(1);
-  __syncthreads();
-#undef REC_STEP_WRITE
 
   // epilogue (as above): C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
   if (out_vec) {
@@ -426,8 +484,256 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
         const float bb = (bias && col < N) ? bias[col] : 0.f;
         const float al = (alpha && col < N) ? alpha[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ot[((r & 3) + 8 * (r >> 2) + 4 * half) * LDO + j * 32 + l32] = act_apply(acc[i][j][r] + bb, act, al);
+        for (int q = 0; q < 16; ++q)
+          ot[((q & 3) + 8 * (q >> 2) + 4 * half) * LDO + j * 32 + l32] = act_apply(acc[i][j][q] + bb, act, al);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = e * 64 + lane, rr = idx >> 4, c4 = idx & 15;
+        const int64_t row = m0 + wm * 64 + i * 32 + rr;
+        const int col = n0 + wn * 64 + 4 * c4;
+        if (row < M && col < N)
+          *reinterpret_cast<f32x4*>(out + row * out_stride + col) = *reinterpret_cast<const f32x4*>(ot + rr * LDO + 4 * c4);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#ifdef REC_DENSE_STAMPS
+    __syncthreads();
+    if (lane == 0 && m0 + wv < M) {
+      float* o = out + (m0 + wv) * out_stride + n0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) o[q] = (float)ph[q];
+      o[6] = (float)((uint32_t)__builtin_amdgcn_s_memtime() - t_entry);
+    }
+#endif
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l32;
+      if (col >= N) continue;
+      const float bb = bias ? bias[col] : 0.f;
+      const float al = alpha ? alpha[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][q] + bb, act, al);
+      }
+    }
+}
+
+// ---- the same again with the operand fragments one k-step ahead in registers (long K) ---------------------------------
+// Ordered stamps of the kernel above (tools/exp/dense_stamps.py, profiles/r03_dense_stamps_pipe2.txt): per wave and k-step,
+// 1080 cycles from the barrier's release until the twelve fragments are in registers, 1034 in the MFMAs, 511 splitting and
+// writing, 222 at the barrier: after every barrier a workgroup's four waves ask the LDS for 48 KB at once and its MFMAs wait
+// (the other two workgroups of the CU fill part of the gap).  Here a wave reads the fragments of step ks + 1 while its
+// MFMAs of step ks run (second fragment set: 223 VGPRs, two workgroups per CU), so the stage written during step ks is the
+// one for step ks + 2:
+//   step ks:  [W DMA (ks + 2) -> stage ks & 1] [x round loads]   fragments(ks + 1) <- stage (ks + 1) & 1
+//             24 MFMAs on fragments(ks), the split of x(ks + 2) between them -> stage ks & 1   vmcnt   barrier
+// Still two LDS stages: a stage is read (into registers) during the step before the one that uses it and rewritten during
+// that one.  x rounds go to two register sets, requested two steps before their first half is split (issue order in an
+// even step [W x3][x x4], in an odd step [W x3]; vmcnt(4) / vmcnt(0) before the barrier: the odd step's wait also covers
+// the round whose first half the next step splits).  The scheduler is told where things go: the fragment reads before
+// the step's MFMAs (left alone it sinks them next to their use, behind the barrier), three of the split's VALU
+// instructions behind each MFMA, the MFMAs term by term over the four accumulators (per accumulator the same order as
+// everywhere: bit-identical results).
+// Against the kernel above on one box (profiles/r03_dense_pipe3_ab.txt): 8192 x 4096 x 4096 211 -> 224 TFLOP/s,
+// 65 536 x 3360 x 256 0.594 -> 0.580 ms, 65 536 x 3456 x 128 0.325 -> 0.328; K <= 1024 0.350 -> 0.354 ms (1024 x 512), 0.346 ->
+// 0.363 (480 x 1024): the longer prologue and the third workgroup it gives up cost more than the hidden reads return, so
+// the dispatch takes it from K = 2048.  With its x loads pinned to L1-resident lines it runs 9 % faster, with the W planes
+// 2 % (r03_dense_pipe3_ablate.txt): what is left is the memory system's rate for 128 scattered x lines per round, not latency.
+__global__ __launch_bounds__(256, 2) void dense_bf16x3_pipe_deep_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ alpha, int act, int64_t M,
+                                                                    int K, int N, float* __restrict__ out,
+                                                                    int64_t out_stride, int out_vec,
+                                                                    const u32x4* __restrict__ Wp, int Np, int xcd_map) {
+  using namespace b3;
+  __shared__ u32x4 frag[2][2][3][2][128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int ntn = (N + BN - 1) / BN;
+  const int64_t ntm = (M + BM - 1) / BM;
+  const int64_t L = blockIdx.x;
+  int64_t mt;
+  int nt_;
+  if (xcd_map) {
+    const int xcd = (int)(L & 7);
+    const int64_t slot = L >> 3;
+    mt = (slot / ntn) * 8 + xcd;
+    nt_ = (int)(slot % ntn);
+  } else {
+    mt = L % ntm;
+    nt_ = (int)(L / ntm);
+  }
+  if (mt >= ntm || nt_ >= ntn) return;
+  const int64_t m0 = mt * BM;
+  const int n0 = nt_ * BN;
+  const int srow = tid & 127, skh = tid >> 7;
+  const int64_t gm = m0 + srow;
+  const float* xbase = x + m0 * x_stride;
+  const uint32_t xoff = (uint32_t)(((gm < M ? srow : 0) * x_stride + 8 * skh) * 4);
+  const u32x4* wbase = Wp + n0;
+  const uint32_t woff = (uint32_t)((skh * 3 * Np + srow) * 16);
+  const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_addr(&frag[0][1][0][skh][srow & 64]));
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  u32x4 xa[2][4];               // [round & 1][step of the round * 2 + piece]
+  bf16x8 fa[2][2][3], fb[2][2][3];   // [step & 1][tile][plane]
+  auto issue_x = [&](int r, u32x4 (&xs)[4]) {
+    const float* px = xbase + r * 2 * BK;
+    gl16s(xs[0], xoff, px, 0);
+    gl16s(xs[1], xoff, px, 16);
+    gl16s(xs[2], xoff, px, BK * 4);
+    gl16s(xs[3], xoff, px, BK * 4 + 16);
+  };
+  auto issue_w = [&](int ks, int st) {
+    const u32x4* pw = wbase + (int64_t)ks * 6 * Np;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(woff), "s"(pw), "s"(pw + Np), "s"(pw + 2 * Np),
+          "s"(__builtin_amdgcn_readfirstlane(wlds + (uint32_t)st * (uint32_t)sizeof(frag[0])))
+        : "memory");
+  };
+  auto lwrite_x = [&](int st, const u32x4& lo, const u32x4& hi) {
+    uint32_t tok;
+    REC_DTOKEN_X2(tok, lo, hi);
+    float av[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = __builtin_bit_cast(float, lo[j] ^ tok), av[4 + j] = __builtin_bit_cast(float, hi[j] ^ tok);
+    u32x4 h, m, l;
+    split8(av, h, m, l);
+    frag[st][0][0][skh][srow] = h;
+    frag[st][0][1][skh][srow] = m;
+    frag[st][0][2][skh][srow] = l;
+  };
+  auto fread = [&](int st, bf16x8 (&a)[2][3], bf16x8 (&b)[2][3]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[t][p] = __builtin_bit_cast(bf16x8, frag[st][0][p][half][wm * 64 + t * 32 + l32]);
+        b[t][p] = __builtin_bit_cast(bf16x8, frag[st][1][p][half][wn * 64 + t * 32 + l32]);
+      }
+  };
+  auto mfmas = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[2][3]) {
+    // term by term over the four accumulators (per accumulator the same order as the kernels above: bit-identical), so that
+    // consecutive MFMAs never depend on each other
+    constexpr int pa[6] = {0, 0, 1, 0, 2, 1}, pb[6] = {0, 1, 0, 2, 0, 1};   // h h, h m, m h, h l, l h, m m
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa[t]], b[j][pb[t]], acc[i][j], 0, 0, 0);
+  };
+  const int nk = K / BK;          // even, >= 2
+  const int nr = nk / 2;
+  // prologue: both stages filled (steps 0 and 1), the fragments of step 0 in registers
+  issue_w(0, 0);
+  issue_w(1, 1);
+  issue_x(0, xa[0]);
+  if (nr > 1) {
+    issue_x(1, xa[1]);
+    REC_VMCNT(4);
+  } else {
+    REC_VMCNT(0);
+  }
+  lwrite_x(0, xa[0][0], xa[0][1]);
+  lwrite_x(1, xa[0][2], xa[0][3]);
+  REC_VMCNT(0);             // round 1 as well: step 0 splits its first half without a wait of its own
+  __syncthreads();
+  fread(0, fa[0], fb[0]);
+  __syncthreads();          // every wave holds step 0's fragments: stage 0 may be refilled
+  // one round = k-steps 2r (fragment set 0) and 2r + 1 (set 1); XS = the x set of round r + 1
+  // the split's ~70 VALU instructions go between the MFMAs (three after each) instead of behind all 24: the matrix pipe
+  // works through an MFMA for 32 cycles, the wave issues its vector work meanwhile
+#define REC_INTERLEAVE()                                                   \
+  do {                                                                     \
+    _Pragma("unroll") for (int g_ = 0; g_ < 24; ++g_) {                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);        \
+    }                                                                      \
+  } while (0)
+#define REC_ROUND3(r, XS, MORE, XNEXT)   /* MORE: a step 2r + 2 exists; XNEXT: a round r + 2 exists */ \
+  do {                                                                               \
+    if (MORE) issue_w(2 * (r) + 2, 0);                                               \
+    if (XNEXT) issue_x((r) + 2, xa[(XS) ^ 1]);                                       \
+    fread(1, fa[1], fb[1]);                                                          \
+    __builtin_amdgcn_sched_barrier(0);   /* the reads go out before this step's MFMAs, not next to their use */ \
+    mfmas(fa[0], fb[0]);                                                             \
+    if (MORE) { lwrite_x(0, xa[XS][0], xa[XS][1]); REC_INTERLEAVE(); }               \
+    if (XNEXT) REC_VMCNT(4); else REC_VMCNT(0);                                      \
+    __syncthreads();                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    if (MORE) {                                                                      \
+      issue_w(2 * (r) + 3, 1);                                                       \
+      fread(0, fa[0], fb[0]);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                             \
+    }                                                                                \
+    mfmas(fa[1], fb[1]);                                                             \
+    if (MORE) {                                                                      \
+      lwrite_x(1, xa[XS][2], xa[XS][3]);                                             \
+      REC_INTERLEAVE();                                                              \
+      REC_VMCNT(0);                                                                  \
+      __syncthreads();                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                             \
+    }                                                                                \
+  } while (0)
+  int r = 0;
+  for (; r + 3 < nr; r += 2) {       // steady state: no conditions inside
+    REC_ROUND3(r, 1, true, true);
+    REC_ROUND3(r + 1, 0, true, true);
+  }
+  // the last one to three rounds
+  if (r < nr) {
+    REC_ROUND3(r, 1, r + 1 < nr, r + 2 < nr);
+    ++r;
+  }
+  if (r < nr) {
+    REC_ROUND3(r, 0, r + 1 < nr, false);
+    ++r;
+  }
+  if (r < nr) REC_ROUND3(r, 1, false, false);
+#undef REC_ROUND3
+#undef REC_INTERLEAVE
+  __syncthreads();      // the epilogue's transpose tile reuses the stages
+
+  if (out_vec) {
+    constexpr int LDO = 64 + 4;
+    float* ot = reinterpret_cast<float*>(&frag[0][0][0][0][0]) + wv * 32 * LDO;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l32;
+        const float bb = (bias && col < N) ? bias[col] : 0.f;
+        const float al = (alpha && col < N) ? alpha[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          ot[((q & 3) + 8 * (q >> 2) + 4 * half) * LDO + j * 32 + l32] = act_apply(acc[i][j][q] + bb, act, al);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -454,15 +760,16 @@ __global__ __launch_bounds__(256, REC_DENSE_PIPE_WG) void dense_bf16x3_pipe_kern
       const float bb = bias ? bias[col] : 0.f;
       const float al = alpha ? alpha[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][r] + bb, act, al);
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][q] + bb, act, al);
       }
     }
 }
+#undef REC_DWAIT_X2
+#undef REC_DSTAMP2
+#undef REC_DTOKEN_X2
 
-#undef REC_DWAIT_X
-#undef REC_DWAIT_W
 
 // W -> [ceil(K/16)*2][3 planes][Np = round_up(N, 128)] bf16x8 fragments (8 consecutive k of one column each)
 __global__ __launch_bounds__(256) void dense_prepare_kernel(const float* __restrict__ W, int K, int N, int Np, int K8,
@@ -527,11 +834,18 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
 #define REC_B3_GO(XM_, BP_)                                                                                      \
   hipLaunchKernelGGL((dense_bf16x3_kernel<XM_, BP_>), grid, dim3(256), 0, st, x, x_stride, W, bias, alpha, act, M, K, \
                      N, out, out_stride, out_vec, wp, Np, xcd_map)
-  // aligned x rows + prepared W + K a multiple of 32: the hand-counted pipeline (rec_debug_force("dense_pipe", "0"): A/B)
-  const bool pipe_ok = !(forced("dense_pipe") && forced("dense_pipe")[0] == '0');
+  // aligned x rows + prepared W + K a multiple of 32: the hand-counted pipelines (their lane offsets are 32-bit);
+  // rec_debug_force("dense_pipe", "0" | "s" | "d"): off / the standard one / the deep one whatever K
+  const char* fp = forced("dense_pipe");
+  const bool pipe_ok = !(fp && fp[0] == '0') && x_stride < (1 << 22) && Np < (1 << 24);
   if (pipe_ok && wp && x_vec == 1 && K % 32 == 0 && K >= 32) {
-    hipLaunchKernelGGL(dense_bf16x3_pipe_kernel, grid, dim3(256), 0, st, x, x_stride, bias, alpha, act, M, K, N, out,
-                       out_stride, out_vec, wp, Np, xcd_map);
+    const bool deep = fp && (fp[0] == 'd' || fp[0] == 's') ? fp[0] == 'd' : K >= 2048;
+    if (deep)
+      hipLaunchKernelGGL(dense_bf16x3_pipe_deep_kernel, grid, dim3(256), 0, st, x, x_stride, bias, alpha, act, M, K, N, out,
+                         out_stride, out_vec, wp, Np, xcd_map);
+    else
+      hipLaunchKernelGGL(dense_bf16x3_pipe_kernel, grid, dim3(256), 0, st, x, x_stride, bias, alpha, act, M, K, N, out,
+                         out_stride, out_vec, wp, Np, xcd_map);
     return true;
   }
   if (wp && x_vec != 2) {  // with the transpose-tile x path the prepared form measured slower (1.10 vs 0.88 ms at K = 3341)

@@ -112,3 +112,32 @@ def test_dense_splitk(dev, M, K, N):
     again = torch.empty_like(out)
     C.dense_splitk_f32(tx.data_ptr(), tx.stride(0), tw.data_ptr(), M, K, N, again.data_ptr(), ws.data_ptr(), st)
     assert torch.equal(out, again)                              # deterministic
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 32, 1), (129, 32, 130), (300, 64, 128), (257, 96, 257), (1000, 480, 1024), (515, 1024, 200),
+                                   (128, 2048, 128), (200, 3360, 136), (70, 4128, 64)])
+def test_dense_hand_counted_pipelines(dev, force, M, K, N):
+    """Aligned x rows, K % 32 == 0: the two hand-counted kernels (W planes by LDS-DMA, x by whole cache lines; "s" standard,
+    "d" with the fragments one step ahead in registers — the dispatch takes it from K = 2048) sum each output's terms in
+    the order of the compiler-scheduled kernel ("0"): bit-identical, and all agree with the fp64 oracle.  One to many
+    rounds, ragged M and N tiles, a row stride wider than K."""
+    from recamd import ops
+    rng = np.random.default_rng(M * 7 + K + N)
+    wide = rng.normal(size=(M, K + 8)).astype(np.float32)
+    W = (rng.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    tx = t(wide)[:, :K]                                   # stride K + 8: still 16-B aligned rows
+    assert tx.stride(0) % 4 == 0
+    tw, tb = t(W), t(b)
+    force("dense", "b")
+    got = {}
+    for arm in ("0", "s", "d"):
+        force("dense_pipe", arm)
+        got[arm] = ops.dense(tx, tw, tb, "relu").cpu().numpy()
+    force("dense_pipe", None)
+    default = ops.dense(tx, tw, tb, "relu").cpu().numpy()
+    assert np.array_equal(got["s"], got["0"]) and np.array_equal(got["d"], got["0"]) and np.array_equal(default, got["0"])
+    x = wide[:, :K]
+    exp = ref.dense(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64), "relu")
+    assert close_scaled(got["s"], exp, np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(b))

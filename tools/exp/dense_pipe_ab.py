@@ -1,35 +1,35 @@
-"""bf16x3 Dense: hand-counted load pipeline (default) vs the compiler-scheduled kernel (REC_DENSE_PIPE=0, child process)."""
-import os, subprocess, sys
+"""The Dense kernels for aligned x / prepared W / K % 32 == 0 side by side on one box, interleaved:
+rec_debug_force("dense_pipe", "0") = the compiler-scheduled kernel, "s" = hand-counted loads (W planes by LDS-DMA, x by
+whole lines), "d" = the same with the fragments one step ahead in registers.  Results must be bit-identical."""
+import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "recommend-tf2.0_amd"))
-
-
-def run():
-    import torch
-    from recamd import ops
-    dev = torch.device("cuda:0")
-
-    def t(fn, it=30):
-        for _ in range(5): fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(it): fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / it
-    for (M, K, N) in [(65536, 512, 256), (65536, 256, 128), (65536, 1024, 1024), (65536, 1024, 512), (65536, 3456, 1024),
-                      (8192, 4096, 4096), (4096, 1024, 1024)]:
-        x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev); b = torch.randn(N, device=dev)
-        out = torch.empty(M, N, device=dev)
-        ms = t(lambda: ops.dense(x, W, b, "relu", out=out))
-        ref = torch.relu(torch.addmm(b.double(), x.double(), W.double())).float() if M * K <= 2 ** 26 else None
-        err = float((out - ref).abs().max() / ref.abs().max()) if ref is not None else -1
-        print(f"M={M} K={K} N={N}: {ms:.3f} ms {2.0*M*K*N/ms/1e9:.1f} TF  rel err {err:.2e}", flush=True)
-
-
-if __name__ == "__main__":
-    if len(sys.argv) > 1:
-        run()
-    else:
-        for v in ("1", "0"):
-            print("REC_DENSE_PIPE=" + v, flush=True)
-            subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, REC_DENSE_PIPE=v))
+from recamd import ops
+from recamd._lib import C
+dev = torch.device("cuda:0")
+ARMS = os.environ.get("ARMS", "0,s,d").split(",")
+def t(fn, it=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+torch.manual_seed(0)
+for (M, K, N) in [(300, 64, 130), (1000, 32, 128), (4099, 96, 256), (65536, 512, 256), (65536, 480, 1024), (65536, 1024, 1024), (65536, 1024, 512),
+                  (65536, 2048, 256), (65536, 3456, 128), (65536, 3360, 256), (8192, 4096, 4096)]:
+    x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev); b = torch.randn(N, device=dev)
+    outs = {}
+    for a in ARMS:
+        C.debug_force("dense_pipe", a)
+        outs[a] = ops.dense(x, W, b, "relu")
+    torch.cuda.synchronize()
+    same = all(bool(torch.equal(outs[ARMS[0]], outs[a])) for a in ARMS[1:])
+    ms = {a: [] for a in ARMS}
+    for rep in range(2):
+        for a in ARMS:
+            C.debug_force("dense_pipe", a)
+            ms[a].append(t(lambda: ops.dense(x, W, b, "relu", out=outs[a])))
+    C.debug_force("dense_pipe", None)
+    fl = 2.0 * M * K * N
+    print(f"M={M} K={K} N={N}: identical={same}  " + "  ".join(f"{a}: {min(ms[a]):.4f} ms ({fl / min(ms[a]) / 1e9:.1f} TF)" for a in ARMS), flush=True)
