@@ -296,6 +296,34 @@ def ncf_forward(P, user, pos, neg, activation="relu"):
     return torch.cat([pl, nl], dim=-1), loss
 
 
+
+def _tower_embed(P, inputs, prefix):
+    """tf.concat([embed_layers['embed_<k>'](v) for k, v in inputs.items()], axis=-1) squeezed to (B, sum of dims):
+    src/match/fm/model.py:63-64,68-69 and src/match/dssm/model.py:68-69,74-75 (dict order; float ids truncate)"""
+    return torch.cat([_table(P, f"{prefix}_embed_{k}/embeddings", np.asarray(v).reshape(-1)) for k, v in inputs.items()], dim=-1)
+
+
+def match_fm_forward(P, user_in, item_in):
+    """src/match/fm/model.py:61-82: FM over the concatenated user / item embeddings -> p (B,)"""
+    stack = torch.cat([_tower_embed(P, user_in, "user"), _tower_embed(P, item_in, "item")], dim=-1)          # :73-75
+    first = P["w0"] + stack @ P["w"]                                                                         # :76
+    Vt = P["V"].T
+    second = 0.5 * torch.sum((stack @ Vt) ** 2 - (stack ** 2) @ (Vt ** 2), dim=1, keepdim=True)              # :77-79
+    return torch.sigmoid(first + second).reshape(-1)                                                         # :80-82
+
+
+def dssm_forward(P, user_in, item_in, activation="relu"):
+    """src/match/dssm/model.py:64-82 -> (y_pred (1,), loss): ONE value for the batch — cosine_similarity (:49-62) flattens both
+    towers' outputs of all samples into one vector each — and the script's objective mean(y_pred)
+    (src/match/dssm/dssm_train.py:47, src/match/utils/loss_util.py:11-13), which ignores the labels"""
+    uo = dense_stack(_tower_embed(P, user_in, "user"), P, "user_dnn", activation)                            # :68-72
+    io = dense_stack(_tower_embed(P, item_in, "item"), P, "item_dnn", activation)                            # :74-77
+    a, b = io.reshape(-1), uo.reshape(-1)
+    cos = torch.sum(a * b) / (torch.sqrt(torch.sum(a * a)) * torch.sqrt(torch.sum(b * b)))                  # :52-60
+    p = torch.sigmoid(cos).reshape(1)                                                                        # :80
+    return p, torch.mean(p)
+
+
 def esmm_forward(P, inputs, user_keys, user_cols, item_keys, item_cols, activation="relu", training=True, new_moving=None):
     """src/ctr/esmm/model.py:37-92 -> (pCTR, pCTCVR).  The shared DNNs' BatchNormalization layers are called once per
     tower: in training mode the second call starts from the moving statistics the first one left (Keras updates them
@@ -326,6 +354,10 @@ def _forward(kind, P, inputs, training, new_moving, kw):
         return deep_crossing_forward(P, inputs), None
     if kind == "ncf":
         return ncf_forward(P, inputs[0], inputs[1], inputs[2])
+    if kind == "match_fm":
+        return match_fm_forward(P, inputs[0], inputs[1]), None
+    if kind == "dssm":
+        return dssm_forward(P, inputs[0], inputs[1])
     if kind == "dlrm":
         return dlrm_forward(P, inputs[0], np.asarray(inputs[1]), kw.get("interaction", "dot"), training=training,
                             new_moving=new_moving), None

@@ -20,6 +20,7 @@ class Dssm(Model):
                  l2_reg_embedding=1e-6, dnn_dropout=0, **kwargs):
         super().__init__()
         self.num_sampled = num_sampled
+        self.embed_reg = l2_reg_embedding                              # :33,42 (recamd.train.default_l2)
         self.user_sparse_feature_columns = user_sparse_feature_columns
         self.user_dense_feature_columns = user_dense_feature_columns
         self.item_sparse_feature_columns = item_sparse_feature_columns

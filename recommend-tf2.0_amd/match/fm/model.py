@@ -21,6 +21,7 @@ class FM(Model):
         self.feature_length = sum(f['embed_dim'] for f in user_sparse_feature_columns) \
             + sum(f['embed_dim'] for f in item_sparse_feature_columns)
         self.k = k
+        self.w_reg, self.v_reg, self.embed_reg = w_reg, v_reg, l2_reg_embedding    # :43,47,56,65 (recamd.train.default_l2)
         self.w0 = self.add_weight('w0', (1,), 'zeros')
         self.w = self.add_weight('w', (self.feature_length, 1), 'random_normal')
         self.V = self.add_weight('V', (self.k, self.feature_length), 'random_normal')

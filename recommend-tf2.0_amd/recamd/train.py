@@ -532,6 +532,13 @@ def dcn_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_sca
 TRAIN_FORWARDS = {"DLRM": dlrm_train_forward, "DeepFM": deepfm_train_forward, "DCN": dcn_train_forward}
 
 
+def train_forward_of(model):
+    """the training-mode forward registered for the model's class: by module-qualified name where two mirrors share a class
+    name (ctr FM / match FM), else by the bare class name; None if there is none"""
+    cls = type(model)
+    return TRAIN_FORWARDS.get(f"{cls.__module__}.{cls.__name__}") or TRAIN_FORWARDS.get(cls.__name__)
+
+
 def default_l2(model) -> Dict[str, float]:
     """the regularisers the reference models attach: embeddings_regularizer=l2(embed_reg) on every table
     (e.g. src/ctr/dlrm/model.py:35, deep_fm/model.py:36, sasrec/model.py:44), the FM layer's l2(w_reg)
@@ -567,8 +574,8 @@ def compute_gradients(model, state: TrainState, inputs, y_true, grad_scale: floa
     """training-mode forward + backward of one batch: (predictions, loss, {name: dense-parameter gradient}); the
     embedding-table gradients are scatter-added into `state`.  loss = mean BCE against y_true, or the model's own
     add_loss when it has no labels (SASRec: y_true = None, predictions = the logits).  `seed` drives the Dropout masks."""
-    from . import train_attn  # noqa: F401  (registers the FM / AutoInt / DIN / SASRec forwards)
-    fwd = TRAIN_FORWARDS[type(model).__name__]
+    from . import train_attn  # noqa: F401  (registers the other mirrors' forwards)
+    fwd = train_forward_of(model)
     tape = Tape(seed)
     if isinstance(y_true, (list, tuple)):          # several targets (ESMM: [ctr, cvr])
         y = [nn.to_device_f32(np.asarray(t, np.float32), model.device) for t in y_true]
@@ -647,8 +654,12 @@ class Trainer:
 
     def __init__(self, model):
         from . import train_attn  # noqa: F401  (registers the FM / AutoInt / DIN / SASRec forwards)
-        if type(model).__name__ not in TRAIN_FORWARDS:
-            raise NotImplementedError(f"no training-mode forward for {type(model).__name__}")
+        if train_forward_of(model) is None:
+            why = ""
+            if type(model).__name__ == "YoutubeDNN":
+                why = (": src/match/youtube_dnn/train.py minimises SampledSoftmaxLayer's tf.nn.sampled_softmax_loss, whose "
+                       "log-uniform sampler is unseeded (src/match/layers/modules.py:43-61) - no reproducible objective to mirror")
+            raise NotImplementedError(f"no training-mode forward for {type(model).__name__}{why}")
         self.model, self.opt, self.state = model, None, TrainState(model)
         self.allreduce, self.world = None, 1
 
@@ -667,13 +678,18 @@ class Trainer:
     # -- helpers
     @staticmethod
     def _slice(x, idx):
+        """rows idx of the inputs: an array, a list of arrays, or (the match models) dicts {feature: (n, 1)} inside a list"""
+        if isinstance(x, dict):
+            return {k: np.asarray(v)[idx] for k, v in x.items()}
         if isinstance(x, (list, tuple)):
-            return [np.asarray(a)[idx] for a in x]
+            return [Trainer._slice(a, idx) for a in x]
         return np.asarray(x)[idx]
 
     @staticmethod
     def _len(x):
-        return len(x[0]) if isinstance(x, (list, tuple)) else len(x)
+        if isinstance(x, dict):
+            return len(next(iter(x.values())))
+        return Trainer._len(x[0]) if isinstance(x, (list, tuple)) else len(x)
 
     def reg_loss_device(self) -> torch.Tensor:
         """sum of the l2 regularisation losses Keras adds to the reported loss — c * sum(w^2) per regularised weight — as a
@@ -703,8 +719,10 @@ class Trainer:
             n, tot = self._len(x), 0.0
             for lo in range(0, n, batch_size):
                 idx = slice(lo, min(n, lo + batch_size))
-                self.model(self._slice(x, idx))
-                tot += float(self.model.losses[-1].item()) * (idx.stop - idx.start)
+                out = self.model(self._slice(x, idx))
+                # the model's add_loss, or — a script whose loss is mean(y_pred) (src/match/utils/loss_util.py:11-13) — its output
+                own = self.model.losses[-1] if getattr(self.model, "losses", None) else out.reshape(-1).mean()
+                tot += float(own.item()) * (idx.stop - idx.start)
             return [tot / n + self.reg_loss()]
         p = torch.from_numpy(self.predict(x, batch_size)).to(self.model.device)
         yt = nn.to_device_f32(np.asarray(y, np.float32).reshape(-1), self.model.device)
@@ -718,6 +736,8 @@ class Trainer:
         batch), `auc` is accumulated over the epoch's training predictions.  Shuffling uses numpy's
         default_rng(seed + epoch).permutation (Keras' own shuffle is unseeded: not reproducible there either).
         y = None: a model whose loss is its own add_loss (SASRec, src/match/sasrec/model.py:93-95) — `loss` only."""
+        if getattr(train_forward_of(self.model), "ignores_labels", False):
+            y = None                   # loss = mean(y_pred): Keras hands the labels to a loss function that drops them
         n = self._len(x)
         n_tr = int(math.floor(n * (1.0 - validation_split)))     # Keras: split_at = floor(n * (1 - validation_split))
         n_val = n - n_tr

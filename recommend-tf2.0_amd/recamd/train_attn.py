@@ -16,7 +16,7 @@ import torch
 
 from . import nn, ops
 from ._lib import C
-from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, concat_cols, dense_fwd, sigmoid_bce, transpose,
+from .train import (TRAIN_FORWARDS, Tape, TrainState, Var, _s, _ws, bn_fwd, colsum, concat_cols, dense_fwd, sigmoid_bce, sum_squares, transpose,
                     weight_grad)
 
 
@@ -593,3 +593,82 @@ def esmm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_sc
 
 TRAIN_FORWARDS.update({"WideDeep": wide_deep_train_forward, "Deep_Crossing": deep_crossing_train_forward,
                        "NCF": ncf_train_forward, "ESMM": esmm_train_forward})
+
+
+# ---- two-tower match models trained by their own scripts: match FM (src/match/fm/train.py), DSSM (src/match/dssm/dssm_train.py) ----
+def _dict_ids(m, inputs: dict) -> torch.Tensor:
+    """{feat: (B, 1)} -> (B, n) int32 ids in dict order (the reference walks `.items()`); float ids truncate like the
+    Keras Embedding cast"""
+    cols = [nn.to_device_f32(v, m.device).reshape(-1, 1) for v in inputs.values()]
+    return torch.cat(cols, dim=1).to(torch.int32).contiguous()
+
+
+def _tower_embed_fwd(tape: Tape, state: TrainState, m, inputs: dict, layers: dict, prefix: str) -> Var:
+    from .train import gather_concat_fwd
+    keys = list(inputs.keys())
+    group = ops.TableGroup([layers['embed_{}'.format(k)].table for k in keys])
+    names = [f"{prefix}_embed_{k}/embeddings" for k in keys]
+    return gather_concat_fwd(tape, state, group, names, _dict_ids(m, inputs))
+
+
+def match_fm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true, grad_scale: float = 1.0):
+    """src/match/fm/model.py:61-82 in training mode (compiled with binary_crossentropy + Adam, src/match/fm/train.py:47).
+    With a = stack V^T:  second = 0.5 (sum_k a_k^2 - stack^2 . vsq), vsq_l = sum_k V_kl^2, so
+    d second / d stack = a V - stack * vsq  and  d second / d V = a^T (dz * stack) - V * colsum(dz * stack^2)."""
+    user_in, item_in = inputs
+    u = _tower_embed_fwd(tape, state, m, user_in, m.user_embed_layers, "user")               # :63-64
+    it = _tower_embed_fwd(tape, state, m, item_in, m.item_embed_layers, "item")              # :68-69
+    stack = concat_fwd(tape, [u, it])                                                       # :73-75
+    w0, w, V = m._w['w0'], m._w['w'], m._w['V']
+    x = stack.v
+    vsq = colsum(V, V)                                                                      # (L,)
+    a = ops.dense(x, transpose(V))                                                          # (B, k)
+    ones = torch.ones((V.shape[0], 1), dtype=torch.float32, device=x.device)
+    first = Var(ops.dense(x, w, w0))                                                        # :76
+    second = Var(ops.axpby_act(ops.dense(ops.mul_act(a, a), ones), ops.dense(ops.mul_act(x, x), vsq.reshape(-1, 1)),
+                               0.5, -0.5, None))                                            # :77-79
+
+    def bwd():
+        dz = first.g.contiguous()                 # = second.g: both logit parts receive the same dL/dz (B, 1)
+        tape.add_grad("w0", colsum(dz))
+        tape.add_grad("w", weight_grad(x, dz))
+        xz = ops.scale_rows(x, dz.reshape(-1))                                               # dz_b * stack_b
+        s = colsum(xz, x)                                                                    # sum_b dz_b stack_bl^2
+        tape.add_grad("V", ops.axpby_act(weight_grad(a, xz), ops.mul_act(V, s.reshape(1, -1).expand_as(V).contiguous()),
+                                         1.0, -1.0, None))
+        dx = ops.axpby_act(ops.dense(dz, transpose(w)), ops.scale_rows(ops.dense(a, V), dz.reshape(-1)), 1.0, 1.0, None)
+        stack.acc(ops.axpby_act(dx, ops.mul_act(xz, vsq.reshape(1, -1).expand_as(x).contiguous()), 1.0, -1.0, None))
+    tape.ops.append(bwd)          # the tape runs backwards: sigmoid_bce's op (appended next) has filled first.g by then
+    return sigmoid_bce(tape, [first, second], y_true, grad_scale)                            # :80-82
+
+
+def dssm_train_forward(tape: Tape, state: TrainState, m, inputs, y_true=None, grad_scale: float = 1.0):
+    """src/match/dssm/model.py:64-82 in training mode with the script's objective, loss = mean(y_pred)
+    (src/match/dssm/dssm_train.py:47, src/match/utils/loss_util.py:11-13): y_pred is the ONE value sigmoid(cos(vec(item
+    tower), vec(user tower))) the model emits for a batch, labels are ignored.  With c = <a, b> / (|a| |b|):
+    dc/da = b / (|a| |b|) - c a / |a|^2 (and symmetrically for b).  Returns (y_pred (1, 1), loss)."""
+    user_in, item_in = inputs
+    ue = _tower_embed_fwd(tape, state, m, user_in, m.user_embed_layers, "user")              # :68-69
+    ie = _tower_embed_fwd(tape, state, m, item_in, m.item_embed_layers, "item")              # :74-75
+    uo = dense_stack_fwd(tape, m.user_dnn.dnn_network, "user_dnn", ue, getattr(m.user_dnn.dropout, "rate", 0.0))   # :72
+    io = dense_stack_fwd(tape, m.item_dnn.dnn_network, "item_dnn", ie, getattr(m.item_dnn.dropout, "rate", 0.0))   # :77
+    a, b = io.v.contiguous(), uo.v.contiguous()
+    p = ops.cosine_flat(a, b, sigmoid=True)                                                  # :79-80
+    loss = p.reshape(())
+
+    def bwd():
+        ab = colsum(colsum(a, b).view(-1, 1))
+        sab, sa2, sb2, pv = [float(v) for v in torch.cat([ab, sum_squares(a), sum_squares(b), p.reshape(1)]).cpu()]
+        inv = 1.0 / ((sa2 ** 0.5) * (sb2 ** 0.5))
+        c = sab * inv
+        g = grad_scale * pv * (1.0 - pv)                                                     # d mean(y_pred) / dc
+        io.acc(ops.axpby_act(b, a, g * inv, -g * c / sa2, None))
+        uo.acc(ops.axpby_act(a, b, g * inv, -g * c / sb2, None))
+    tape.ops.append(bwd)
+    return p.reshape(1, 1), loss
+
+
+dssm_train_forward.ignores_labels = True
+
+# keyed by module-qualified class name where a bare name is taken (ctr FM / match FM)
+TRAIN_FORWARDS.update({"match.fm.model.FM": match_fm_train_forward, "Dssm": dssm_train_forward})

@@ -562,3 +562,58 @@ def test_esmm_training_step_two_targets_shared_towers(dev):
         assert close(p[0].cpu().numpy().reshape(-1), ep[0], floor=1.0) and close(p[1].cpu().numpy().reshape(-1), ep[1], floor=1.0)
         assert abs(float(loss.item()) - eloss) <= 1e-5 * max(1.0, abs(eloss))
     check_weights(m, W, lr)
+
+
+# ---- the two-tower match models with their own train scripts: match FM, DSSM (YoutubeDNN's objective is an unseeded sampler) ----
+def _two_tower_inputs(rng, B):
+    ufeat = [{'feat': 'user_id', 'feat_num': 40, 'feat_len': 1, 'embed_dim': 8}, {'feat': 'age', 'feat_num': 7, 'feat_len': 1, 'embed_dim': 4}]
+    ifeat = [{'feat': 'movie_id', 'feat_num': 50, 'feat_len': 1, 'embed_dim': 8}, {'feat': 'genre', 'feat_num': 5, 'feat_len': 1, 'embed_dim': 4}]
+    user = {f['feat']: rng.integers(0, f['feat_num'], size=(B, 1)).astype(np.float32) for f in ufeat}
+    item = {f['feat']: rng.integers(0, f['feat_num'], size=(B, 1)).astype(np.float32) for f in ifeat}
+    return ufeat, ifeat, user, item
+
+
+def test_match_fm_training_step(dev):
+    """src/match/fm/train.py:43-58: binary cross-entropy + Adam on the match FM — w0, w, V and the four tables after two
+    steps against the fp64 autograd oracle (l2 on w, V and the tables as the model attaches them, src/match/fm/model.py:43-65)"""
+    from match.fm.model import FM
+    from recamd import train as tr
+    from tests.test_models_gpu import randomize
+    rng = np.random.default_rng(60)
+    B = 96
+    ufeat, ifeat, user, item = _two_tower_inputs(rng, B)
+    y = (rng.random(B) < 0.5).astype(np.float32)
+    m = FM(ufeat, ifeat, k=6, w_reg=1e-3, v_reg=1e-3, l2_reg_embedding=1e-4)
+    m([user, item])
+    randomize(m, rng, 0.3)
+    l2 = run_steps(m, "match_fm", {}, [user, item], y)
+    assert l2 == {"/embeddings": 1e-4, "w": 1e-3, "V": 1e-3}
+    assert tr.train_forward_of(m).__name__ == "match_fm_train_forward"
+
+
+def test_dssm_training_step_and_fit(dev):
+    """src/match/dssm/dssm_train.py:43-60: loss = mean(y_pred), the ONE sigmoid(cosine) value the model emits per batch
+    (dropout 0 for the parity check; the script uses 0.5).  Two Adam steps against the oracle, then fit() with the
+    script's arguments on dict inputs: labels are accepted and ignored, the loss falls (it is being minimised)."""
+    from match.dssm.model import Dssm
+    from recamd import train as tr
+    from tests.test_models_gpu import randomize
+    rng = np.random.default_rng(61)
+    B = 80
+    ufeat, ifeat, user, item = _two_tower_inputs(rng, B)
+    m = Dssm(ufeat, ifeat, user_dnn_hidden_units=(16, 8), item_dnn_hidden_units=(16, 8), l2_reg_embedding=1e-4)
+    m([user, item])
+    randomize(m, rng, 0.3)
+    run_steps(m, "dssm", {}, [user, item], None)
+    t = tr.Trainer(m).compile(learning_rate=1e-2)
+    hist = t.fit([user, item], (rng.random(B) < 0.5).astype(np.float32), batch_size=32, epochs=4, validation_split=0.1)
+    assert set(hist) == {"loss", "val_loss"} and hist["loss"][-1] < hist["loss"][0]
+    assert np.isfinite(t.evaluate([user, item])[0])
+
+
+def test_youtube_dnn_has_no_trainer(dev):
+    from match.youtube_dnn.model import YoutubeDNN
+    from recamd import train as tr
+    ufeat, ifeat, _, _ = _two_tower_inputs(np.random.default_rng(0), 4)
+    with pytest.raises(NotImplementedError, match="unseeded"):
+        tr.Trainer(YoutubeDNN(ufeat, ifeat))
