@@ -5,7 +5,7 @@ from recamd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 # Dense layers of the DLRM top MLP (pipelined bf16x3 kernel) and a square GEMM
-for (M, K, N) in [(65536, 1024, 1024), (65536, 1024, 512), (65536, 480, 1024), (8192, 4096, 4096)]:
+for (M, K, N) in [(65536, 1024, 1024), (65536, 1024, 512), (65536, 480, 1024), (65536, 3360, 256), (8192, 4096, 4096)]:
     x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev); b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
     for _ in range(12):

@@ -8,23 +8,27 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_mfma
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc" -o w -- python3 "$ROOT/tools/exp/mfma_workload.py" > "$OUT/run.log" 2>&1
+# calibration: the same counters over the pure-MFMA probe (tools/exp/mfma_peak: registers only / + LDS reads / + full LDS traffic)
+if [ -x "$ROOT/tools/exp/mfma_peak" ]; then
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_probe" -o w -- "$ROOT/tools/exp/mfma_peak" 3 512 > "$OUT/probe.log" 2>&1 || echo "probe pass failed"
+fi
 python3 - "$OUT" "$ROOT/gpurun_out/${TAG}_pmc_mfma_util.json" <<'PY'
 import collections, csv, glob, json, sys
 out, dst = sys.argv[1], sys.argv[2]
-cc = glob.glob(out + "/pmc/**/*counter_collection.csv", recursive=True)[0]
-kt = glob.glob(out + "/pmc/**/*kernel_trace.csv", recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-for r in csv.DictReader(open(cc)):
-    a = agg[r["Kernel_Name"]][r["Counter_Name"]]
-    a[0] += float(r["Counter_Value"]); a[1] += 1
 dur = collections.defaultdict(lambda: [0.0, 0])
-if kt:
-    for r in csv.DictReader(open(kt[0])):
-        d = dur[r["Kernel_Name"]]
-        d[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; d[1] += 1
+for sub in ("pmc", "pmc_probe"):
+    for cc in glob.glob(out + "/" + sub + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(cc)):
+            a = agg[r["Kernel_Name"]][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    for kt in glob.glob(out + "/" + sub + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(kt)):
+            d = dur[r["Kernel_Name"]]
+            d[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; d[1] += 1
 res = {}
 for k, cs in agg.items():
-    if "rec::" not in k or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs:
+    if ("rec::" not in k and "probe<" not in k) or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs:
         continue
     busy = cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / cs["SQ_VALU_MFMA_BUSY_CYCLES"][1]
     act = cs["GRBM_GUI_ACTIVE"][0] / cs["GRBM_GUI_ACTIVE"][1]
