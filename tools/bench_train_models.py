@@ -58,6 +58,28 @@ def main():
     from ctr.wide_deep.model import WideDeep
     from match.sasrec.model import SASRec
     from match.ncf.model import NCF
+    if os.environ.get("FULL") == "1":
+        # BASELINE configs[1] at its real size: 26 x 1M x 128 tables (13.3 GB of weights, as much again for each Adam moment and
+        # for the dense gradient arena), batch 65 536 — the exact Keras-Adam step touches every row, the lazy one ~1.7 M of them
+        Vf, Bf2 = 1_000_000, 65536
+        sp = [{'feat': f'C{i}', 'feat_num': Vf, 'embed_dim': 128} for i in range(F)]
+        dn = torch.rand((Bf2, nd), device="cuda:0")
+        idf2 = torch.randint(0, Vf, (Bf2, F), device="cuda:0", dtype=torch.int32)
+        yf = (torch.rand(Bf2, device="cuda:0") < 0.3).float()
+        m = DLRM([densec, sp], [512, 256, 128], [1024, 1024, 512, 256], interaction='dot')
+        m([dn, idf2])
+        params = sum(v.numel() for v in tr.named_weights(m).values())
+        out = {"batch": Bf2, "parameters": params}
+        ms = step_time(m, [dn, idf2], yf, steps=4, sparse=True)
+        out["lazy_rowwise_adam"] = {"ms_per_step": round(ms, 3), "samples_per_s": round(Bf2 / ms * 1e3, 1)}
+        print("lazy", out, flush=True)
+        torch.cuda.empty_cache()
+        ms = step_time(m, [dn, idf2], yf, steps=3)
+        out["exact_dense_adam"] = {"ms_per_step": round(ms, 3), "samples_per_s": round(Bf2 / ms * 1e3, 1),
+                                   "GB_touched_per_step": round(params * 28 / 1e9, 1)}
+        out["peak_device_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
+        print(json.dumps({"DLRM dot 26x1Mx128, batch 65536 (configs[1] size)": out}))
+        return
     m = DLRM([densec, sparse128], [512, 256, 128], [1024, 512, 256], interaction='dot')
     m([dense, ids]); rec("DLRM dot 26x100kx128", m, [dense, ids], y, B, True)
     m = DeepFM([densec, sparse128], (256, 128, 64))
