@@ -54,12 +54,18 @@ constexpr int kWaves = REC_SASREC_WAVES;   // per workgroup (one workgroup per C
 #define REC_SASREC_KU 4
 #endif
 constexpr int kU = REC_SASREC_KU;   // row-load instructions per landing buffer (4 rows each)
-// landing buffers per wave (16 rows each at kU = 4).  Attention phase: the matvec chain's values are live beside them.
-// Candidate phase: almost nothing else is live, so more buffers fit the same register budget — and every buffer more is
-// 16 more rows in flight per wave, i.e. fewer HBM round trips in the sample's serial chain (round 3).
+// landing buffers per wave (16 rows each at kU = 4), attention phase x candidate phase.  Round 3, same-box A/Bs with every
+// arm checked against the oracle (tools/exp/sasrec_bufs_ab.sh, profiles/r03_sasrec_bufs_ab*.txt): 1 x 2 (shipped) 81.3 /
+// 84.3 us against 82.6 / 85.7 for 2 x 2; 1 x 3, 1 x 2 with 5 or 6 loads per buffer 81.5 - 82.0; 1 x 1 with 7 loads 85.8;
+// 2 x 4, 3 x 4, 4 x 4 82.9 / 84.9 / 99.1.  More rows in flight per wave do not help: ~33 MB of row requests are outstanding
+// chip-wide, the memory system is saturated for this pattern — touching the candidate rows ahead (LDS-DMA of 4 B per lane
+// into a dead buffer while the matvec chain runs) costs 14 % (r03_sasrec_touch_ab.txt), and a batch with every sample at
+// the mean length is only 6 % faster (r03_sasrec_lens_ab.txt).  (An arm that indexes a landing buffer it does not have
+// compiles, skips that buffer's loads and looks 10 % faster: hence the oracle check per arm.)
 #ifndef REC_SASREC_ATT_BUFS
-#define REC_SASREC_ATT_BUFS 2
+#define REC_SASREC_ATT_BUFS 1
 #endif
+
 #ifndef REC_SASREC_CAND_BUFS
 #define REC_SASREC_CAND_BUFS 2
 #endif
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(kWaves * 64) void sasrec_last_row_kernel(
       }
     };
     issue_cand(kbuf[0], 0);
-    issue_cand(kbuf[1], 4 * kU);
+    if constexpr (kNC > 1) issue_cand(kbuf[1 % kNB], 4 * kU);
     // merge the four group states
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
