@@ -294,7 +294,12 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
                            const float* alpha, int act, int64_t M, int K, int N, float* out, int64_t out_stride,
                            hipStream_t st);
 int64_t dense_prepared_bytes(int K, int N);
+int64_t dense_b3_prepared_bytes(int K, int N);
 void dense_prepare_launch(const float* W, int K, int N, void* Wp, hipStream_t st);
+bool dense_f16x2_dispatch(const float* x, int64_t x_stride, const void* Wq, const float* bias, const float* alpha, int act,
+                          int64_t M, int K, int N, float* out, int64_t out_stride, float* absmax, int absmax_valid,
+                          float* out_absmax, hipStream_t st);
+void row_absmax_launch(const float* x, int64_t x_stride, int64_t M, int K, float* absmax, hipStream_t st);
 
 bool dense_b3_rows_dispatch(const float* x, int64_t x_stride, const float* W, const float* bias, const float* alpha,
                             int act, int64_t M, int K, int N, float* out, int64_t out_stride, hipStream_t st);
@@ -449,4 +454,53 @@ extern "C" int rec_dense_prep_f32(const float* x, int64_t x_stride, const float*
   REC_CHECK_ARG(!prepared || aligned16(prepared), REC_EINVAL, "rec_dense_prep_f32: prepared not 16-B aligned");
   return dense_impl_f32("rec_dense_prep_f32", x, x_stride, W, prepared, bias, alpha, act, M, K, N, out, out_stride,
                         stream);
+}
+
+// rec_dense_prep_f32 with one float of workspace per row: large layers whose shape the f16x2 kernel covers (aligned x rows,
+// K % 32 == 0, prepared weights reported usable) run on it — three f16 MFMAs per product instead of six bf16 ones, same
+// accuracy (csrc/dense_f16x2.hip); everything else is rec_dense_prep_f32.  The pass over x that finds the row maxima costs
+// 4 M K bytes of reading against ~a quarter of the GEMM's time saved: it pays from N = 384 (measured: 65 536 x 3456 x 128 is
+// 28 % slower with it, x 1024 27 % faster), so narrower layers take the kernel only when their producer delivered the maxima
+// (absmax_valid).  rec_debug_force("dense_pipe", "0" | "s" | "d") or any forced "dense" kernel keeps the other kernels;
+// "h" takes this one whatever N.
+extern "C" int rec_dense_prep_rs_f32(const float* x, int64_t x_stride, const float* W, const void* prepared,
+                                     const float* bias, const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
+                                     float* out, int64_t out_stride, float* row_absmax, int32_t absmax_valid,
+                                     float* out_absmax, void* stream) {
+  const char* who = "rec_dense_prep_rs_f32";
+  REC_CHECK_ARG(!prepared || aligned16(prepared), REC_EINVAL, "%s: prepared not 16-B aligned", who);
+  const char* fp = forced("dense_pipe");
+  const bool other = dense_impl() != 0 || (fp && (fp[0] == '0' || fp[0] == 's' || fp[0] == 'd'));
+  const bool pays = absmax_valid || N >= 384 || (fp && fp[0] == 'h');
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (prepared && row_absmax && !other && pays && x && W && out && M >= 1024 && N > 8 && K >= 32 && x_stride >= K &&
+      out_stride >= N && act >= REC_ACT_NONE && act <= REC_ACT_PRELU && (act != REC_ACT_PRELU || alpha)) {
+    const void* Wq = static_cast<const char*>(prepared) + dense_b3_prepared_bytes(K, N);
+    if (dense_f16x2_dispatch(x, x_stride, Wq, bias, alpha, act, M, K, N, out, out_stride, row_absmax, absmax_valid, out_absmax,
+                             st)) {
+      REC_CHECK_LAUNCH(who);
+      return REC_OK;
+    }
+  }
+  const int rc = dense_impl_f32(who, x, x_stride, W, prepared, bias, alpha, act, M, K, N, out, out_stride, stream);
+  if (rc == REC_OK && out_absmax && M > 0) {      // another kernel answered: the maxima come from a pass over its output
+    row_absmax_launch(out, out_stride, M, N, out_absmax, st);
+    REC_CHECK_LAUNCH(who);
+  }
+  return rc;
+}
+
+// 1 when the prepared weights can serve the f16x2 kernel (every column maximum within 2^+-40, all weights finite), else 0.
+// Copies one word to the host and waits for the stream: call it once per prepared buffer.
+extern "C" int rec_dense_f16x2_usable(const void* prepared, int32_t K, int32_t N, int32_t* usable, void* stream) {
+  const char* who = "rec_dense_f16x2_usable";
+  REC_CHECK_ARG(prepared && usable && K >= 1 && N >= 1, REC_EINVAL, "%s: bad argument", who);
+  const int64_t K8 = (int64_t)((K + 15) / 16) * 2, Np = (N + 127) / 128 * 128;
+  const char* flag = static_cast<const char*>(prepared) + dense_b3_prepared_bytes(K, N) + K8 * 2 * Np * 16 + Np * 4;
+  uint32_t v = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  REC_CHECK_ARG(hipMemcpyAsync(&v, flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess,
+                REC_EINVAL, "%s: copy failed", who);
+  *usable = v == 1u ? 1 : 0;
+  return REC_OK;
 }

@@ -860,16 +860,21 @@ bool dense_bf16x3_dispatch(const float* x, int64_t x_stride, const float* W, con
   return true;
 }
 
-int64_t dense_prepared_bytes(int K, int N) {
+// the prepared buffer: [bf16x3 planes][f16x2 planes + inverse column scales + usable flag (csrc/dense_f16x2.hip)]
+int64_t dense_f16x2_bytes(int K, int N);
+void dense_f16x2_prepare_launch(const float* W, int K, int N, void* Wq, hipStream_t st);
+int64_t dense_b3_prepared_bytes(int K, int N) {
   const int64_t K8 = (int64_t)((K + 15) / 16) * 2, Np = (N + 127) / 128 * 128;
   return K8 * 3 * Np * 16;
 }
+int64_t dense_prepared_bytes(int K, int N) { return dense_b3_prepared_bytes(K, N) + dense_f16x2_bytes(K, N); }
 
 void dense_prepare_launch(const float* W, int K, int N, void* Wp, hipStream_t st) {
   const int K8 = (K + 15) / 16 * 2, Np = (N + 127) / 128 * 128;
   const int64_t total = (int64_t)K8 * Np;
   hipLaunchKernelGGL(dense_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, K, N, Np, K8,
                      static_cast<u32x4*>(Wp));
+  dense_f16x2_prepare_launch(W, K, N, static_cast<char*>(Wp) + dense_b3_prepared_bytes(K, N), st);
 }
 
 }  // namespace rec

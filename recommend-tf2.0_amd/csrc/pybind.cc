@@ -140,6 +140,20 @@ PYBIND11_MODULE(_C, m) {
                              P<void>(stream)),
           "rec_dense_prep_f32");
   });
+  m.def("dense_prep_rs_f32", [](ptr_t x, int64_t x_stride, ptr_t W, ptr_t prepared, ptr_t bias, ptr_t alpha, int act,
+                                int64_t M, int K, int N, ptr_t out, int64_t out_stride, ptr_t row_absmax, int absmax_valid,
+                                ptr_t out_absmax, ptr_t stream) {
+    py::gil_scoped_release nogil;
+    check(rec_dense_prep_rs_f32(P<const float>(x), x_stride, P<const float>(W), P<const void>(prepared),
+                                P<const float>(bias), P<const float>(alpha), act, M, K, N, P<float>(out), out_stride,
+                                P<float>(row_absmax), absmax_valid, P<float>(out_absmax), P<void>(stream)),
+          "rec_dense_prep_rs_f32");
+  });
+  m.def("dense_f16x2_usable", [](ptr_t prepared, int K, int N, ptr_t stream) {
+    int32_t u = 0;
+    check(rec_dense_f16x2_usable(P<const void>(prepared), K, N, &u, P<void>(stream)), "rec_dense_f16x2_usable");
+    return (int)u;
+  });
   m.def("mha_ctr_f32", [](ptr_t xq, ptr_t xk, ptr_t xv, int64_t B, int N, int din, ptr_t Wq,
                           ptr_t Wk, ptr_t Wv, ptr_t W0, int H, int S, int act, ptr_t out,
                           ptr_t stream) {

@@ -73,24 +73,17 @@ class DNN(nn.Layer):
         16-B aligned view of a concat buffer; the zero pad column of a row stride rounded up to 4 floats); the folded
         first-layer kernel gets as many zero rows, so the product is unchanged and the GEMM stays on its aligned path
         (K a multiple of 32 takes the pipelined kernel)."""
-        x = inputs
-        n = len(self.dnn_network)
-        for i, layer in enumerate(self.dnn_network):
-            o = out if i == n - 1 else None
-            if i == 0:
-                if not layer.built:
-                    layer.build(x.shape[-1] - lead_pad - tail_pad)
-                key = (self._version, self.bn._version, layer._version, lead_pad, tail_pad)
-                if self._folded is None or self._folded[0] != key:
-                    Wf, bf = self.bn.fold(layer._w['kernel'], layer._w.get('bias'))
-                    if lead_pad or tail_pad:
-                        z = lambda r: torch.zeros((r, Wf.shape[1]), dtype=Wf.dtype, device=Wf.device)  # noqa: E731
-                        Wf = torch.cat([z(lead_pad), Wf, z(tail_pad)], dim=0).contiguous()
-                    self._folded = (key, (Wf, bf))
-                Wf, bf = self._folded[1]
-                x = layer.apply(x, Wf, bf, out=o)
-            else:
-                x = layer(x, out=o)
+        layer = self.dnn_network[0]
+        if not layer.built:
+            layer.build(inputs.shape[-1] - lead_pad - tail_pad)
+        key = (self._version, self.bn._version, layer._version, lead_pad, tail_pad)
+        if self._folded is None or self._folded[0] != key:
+            Wf, bf = self.bn.fold(layer._w['kernel'], layer._w.get('bias'))
+            if lead_pad or tail_pad:
+                z = lambda r: torch.zeros((r, Wf.shape[1]), dtype=Wf.dtype, device=Wf.device)  # noqa: E731
+                Wf = torch.cat([z(lead_pad), Wf, z(tail_pad)], dim=0).contiguous()
+            self._folded = (key, (Wf, bf))
+        x = nn.dense_chain(self.dnn_network, inputs, out=out, first=self._folded[1])
         return self.dropout(x)
 
 

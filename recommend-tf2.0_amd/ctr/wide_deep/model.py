@@ -30,19 +30,18 @@ class DNN(nn.Layer):
     def call(self, inputs, tail_pad=0, **kwargs):
         """tail_pad > 0: `inputs` carries that many ZERO columns behind the features (a row stride rounded up so that
         K % 32 == 0); the first layer's kernel gets as many zero rows, the product is unchanged."""
-        x = inputs
-        for i, dnn in enumerate(self.dnn_network):
-            if i == 0 and tail_pad:
-                if not dnn.built:
-                    dnn.build(x.shape[-1] - tail_pad)
-                key = (dnn._version, tail_pad)
-                if self._padded is None or self._padded[0] != key:
-                    W = dnn._w['kernel']
-                    z = torch.zeros((tail_pad, W.shape[1]), dtype=W.dtype, device=W.device)
-                    self._padded = (key, torch.cat([W, z], dim=0).contiguous())
-                x = dnn.apply(x, self._padded[1], dnn._w.get('bias'))
-            else:
-                x = dnn(x)
+        first = None
+        dnn = self.dnn_network[0]
+        if tail_pad:
+            if not dnn.built:
+                dnn.build(inputs.shape[-1] - tail_pad)
+            key = (dnn._version, tail_pad)
+            if self._padded is None or self._padded[0] != key:
+                W = dnn._w['kernel']
+                z = torch.zeros((tail_pad, W.shape[1]), dtype=W.dtype, device=W.device)
+                self._padded = (key, torch.cat([W, z], dim=0).contiguous())
+            first = (self._padded[1], dnn._w.get('bias'))
+        x = nn.dense_chain(self.dnn_network, inputs, first=first)
         return self.dropout(x)
 
 

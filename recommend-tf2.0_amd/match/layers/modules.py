@@ -17,6 +17,8 @@ class DNN(nn.Layer):
         self.dropout = nn.Dropout(dnn_dropout)
 
     def call(self, inputs, **kwargs):
+        if inputs.dim() == 2:
+            return self.dropout(nn.dense_chain(self.dnn_network, inputs))    # row maxima handed from layer to layer
         x = inputs
         for dnn in self.dnn_network:
             x = dnn(x)

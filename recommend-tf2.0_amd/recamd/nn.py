@@ -180,19 +180,41 @@ class Dense(Layer):
             self._children["dice"] = self.activation
         self.built = True
 
-    def call(self, x, out=None, **kwargs):
+    def call(self, x, out=None, row_absmax=None, want_absmax=False, **kwargs):
         if not self.built:
             self.build(x.shape[-1])
         W, b = self._w["kernel"], self._w.get("bias")
-        return self.apply(x, W, b, out=out)
+        return self.apply(x, W, b, out=out, row_absmax=row_absmax, want_absmax=want_absmax)
 
-    def apply(self, x, W, b, out=None):
+    def apply(self, x, W, b, out=None, row_absmax=None, want_absmax=False):
+        """row_absmax / want_absmax: the row maxima ops.dense's large-layer kernel scales by, handed from layer to layer
+        (dense_chain) so that no layer re-reads its input to find them; want_absmax returns (out, maxima of out's rows)"""
         act = self.activation
         if isinstance(act, PReLU):
-            return ops.dense(x, W, b, "prelu", act._w["alpha"], out=out)
+            return ops.dense(x, W, b, "prelu", act._w["alpha"], out=out, row_absmax=row_absmax, want_absmax=want_absmax)
         if isinstance(act, Dice):
-            return act(ops.dense(x, W, b, None, out=out))
-        return ops.dense(x, W, b, act, out=out)
+            y = act(ops.dense(x, W, b, None, out=out, row_absmax=row_absmax))
+            return (y, None) if want_absmax else y
+        return ops.dense(x, W, b, act, out=out, row_absmax=row_absmax, want_absmax=want_absmax)
+
+
+def dense_chain(layers, x, out=None, first=None):
+    """x -> layers[0] -> layers[1] -> ... (a tower's Dense stack).  Between two large layers the producer's epilogue delivers
+    the row maxima the consumer's kernel scales by (csrc/dense_f16x2.hip).  first: optional (W, b) that replaces the first
+    layer's own kernel / bias (a folded BatchNormalization, zero rows for pad columns)."""
+    n = len(layers)
+    am = None
+    for i, layer in enumerate(layers):
+        o = out if i == n - 1 else None
+        # the next layer takes the scaled kernel only when it is large: rows >= 1024, K = this layer's width a multiple of 32
+        want = (i + 1 < n and x.shape[0] >= 1024 and x.dim() == 2 and layer.units % 32 == 0 and layer.units >= 64
+                and layers[i + 1].units > 8 and not isinstance(layer.activation, Dice))
+        if i == 0 and first is not None:
+            y = layer.apply(x, first[0], first[1], out=o, row_absmax=am, want_absmax=want)
+        else:
+            y = layer(x, out=o, row_absmax=am, want_absmax=want)
+        x, am = y if want else (y, None)
+    return x
 
 
 class PReLU(Layer):

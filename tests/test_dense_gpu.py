@@ -141,3 +141,151 @@ def test_dense_hand_counted_pipelines(dev, force, M, K, N):
     x = wide[:, :K]
     exp = ref.dense(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64), "relu")
     assert close_scaled(got["s"], exp, np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(b))
+
+
+def _h2_case(rng, M, K, N, xscale=None, wscale=None):
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    W = (rng.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
+    if xscale is not None:
+        x = (x * xscale).astype(np.float32)
+    if wscale is not None:
+        W = (W * wscale).astype(np.float32)
+    return x, W, rng.normal(size=N).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 32, 128), (1500, 64, 130), (2048, 512, 256), (1100, 1024, 200), (1024, 2048, 136), (4099, 96, 12)])
+@pytest.mark.parametrize("act", [None, "relu", "prelu"])
+def test_dense_f16x2_matches_the_oracle_and_the_other_kernels(dev, force, M, K, N, act):
+    """csrc/dense_f16x2.hip (the default for large layers with aligned rows and K % 32 == 0): rows of x and columns of W scaled
+    by exact powers of two, two f16 terms each, three MFMAs per product.  Against fp64 it must be at the level of the fp32-MFMA
+    kernel (an fmaf chain) and of the bf16x3 kernel, on ragged tiles, with bias / activations, and deterministic."""
+    from recamd import ops
+    rng = np.random.default_rng(M + K + N)
+    x, W, b = _h2_case(rng, M, K, N)
+    alpha = rng.random(N).astype(np.float32) if act == "prelu" else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)  # noqa: E731
+    tx, tw, tb, ta = t(x), t(W), t(b), t(alpha)
+    exp = ref.dense(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64), act, alpha)
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(b)
+    force("dense_pipe", "h")                                                 # f16x2 whatever N (by default: N >= 384, or row maxima handed over)
+    got = ops.dense(tx, tw, tb, act, ta).cpu().numpy()
+    again = ops.dense(tx, tw, tb, act, ta).cpu().numpy()
+    assert np.array_equal(got, again)
+    assert close_scaled(got, exp, scale)
+    force("dense_pipe", "s")
+    got_b = ops.dense(tx, tw, tb, act, ta).cpu().numpy()                     # bf16x3, hand-counted
+    force("dense_pipe", None)
+    force("dense", "f")
+    got_f = ops.dense(tx, tw, tb, act, ta).cpu().numpy()                     # fp32 MFMA
+    if N > 12:
+        assert not np.array_equal(got, got_b)                                # it really is another kernel
+    err, err_b, err_f = (np.abs(g - exp).max() for g in (got, got_b, got_f))
+    assert err <= 2.0 * max(err_f, err_b) + 1e-7, (err, err_b, err_f)
+
+
+def test_dense_f16x2_ranges(dev, force):
+    """Per-row and per-column scaling: rows of x 2^-60 .. 2^60 apart and columns of W 2^-30 .. 2^30 apart keep fp32-level
+    accuracy relative to their own magnitudes; values spanning 2^-20 .. 2^10 INSIDE a row keep the bound of the bf16x3 test;
+    a zero row and a zero column give exact zeros (+ bias)."""
+    from recamd import ops
+    force("dense_pipe", "h")
+    rng = np.random.default_rng(77)
+    M, K, N = 1024, 128, 96
+    x, W, b = _h2_case(rng, M, K, N, xscale=np.exp2(rng.integers(-60, 61, size=(M, 1))), wscale=np.exp2(rng.integers(-30, 31, size=(1, N))))
+    x[5] = 0.0
+    W[:, 7] = 0.0
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    got = ops.dense(t(x), t(W)).cpu().numpy().astype(np.float64)
+    exp = x.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64)
+    assert np.all(got[5] == 0.0) and np.all(got[:, 7] == 0.0)
+    assert np.all(np.abs(got - exp) <= 2e-6 * scale + 1e-300)
+    x2 = (rng.normal(size=(M, K)) * np.exp2(rng.integers(-20, 11, size=(M, K)))).astype(np.float32)
+    W2 = (rng.normal(size=(K, N)) * np.exp2(rng.integers(-10, 3, size=(K, N)))).astype(np.float32)
+    got2 = ops.dense(t(x2), t(W2)).cpu().numpy()
+    exp2 = x2.astype(np.float64) @ W2.astype(np.float64)
+    scale2 = np.abs(x2.astype(np.float64)) @ np.abs(W2.astype(np.float64))
+    assert np.all(np.abs(got2 - exp2) <= 2e-6 * scale2 + 1e-30)
+
+
+def test_dense_f16x2_falls_back_for_weights_out_of_range(dev):
+    """a column of W around 2^50: the prepared form reports itself unusable and the bf16x3 kernels answer (still right)"""
+    from recamd import ops
+    from recamd._lib import C
+    rng = np.random.default_rng(78)
+    M, K, N = 1024, 64, 128
+    x, W, b = _h2_case(rng, M, K, N)
+    W[:, 3] *= np.float32(2.0 ** 50)
+    tw = torch.from_numpy(W).to(dev)
+    prep, usable = ops._prepared_weights(tw)
+    assert not usable
+    got = ops.dense(torch.from_numpy(x).to(dev), tw, torch.from_numpy(b).to(dev)).cpu().numpy()
+    exp = x.astype(np.float64) @ W.astype(np.float64) + b
+    assert close_scaled(got, exp, np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(b))
+    W[:, 3] = rng.normal(size=K).astype(np.float32)
+    assert ops._prepared_weights(torch.from_numpy(W).to(dev))[1]
+
+
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
+def test_dense_f16x2_nonfinite_rows(dev, force, bad):
+    """the contract of tests/test_nonfinite_gpu.py on the default path: a poisoned row is non-finite everywhere, every other
+    row is bit-identical to the clean run; fp32 denormals are lost to within their own magnitude"""
+    from recamd import ops
+    force("dense_pipe", "h")
+    rng = np.random.default_rng(3)
+    M, K, N = 2048, 256, 128
+    x, W, _ = _h2_case(rng, M, K, N)
+    W[7, :] = 0.5
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    clean = ops.dense(t(x), t(W)).cpu().numpy()
+    xb = x.copy()
+    xb[100, 7] = bad
+    xb[1500, 200] = bad
+    got = ops.dense(t(xb), t(W)).cpu().numpy()
+    assert not np.isfinite(got[100]).any() and not np.isfinite(got[1500]).any()
+    rest = np.ones(M, bool)
+    rest[[100, 1500]] = False
+    assert np.array_equal(got[rest].view(np.uint32), clean[rest].view(np.uint32))
+    xd = x.copy()
+    xd[:, :16] = (rng.random((M, 16)) * 1e-39).astype(np.float32)
+    gd = ops.dense(t(xd), t(W)).cpu().numpy()
+    ed = xd.astype(np.float64) @ W.astype(np.float64)
+    assert np.isfinite(gd).all()
+    assert close_scaled(gd, ed, np.abs(xd).astype(np.float64) @ np.abs(W).astype(np.float64))
+
+
+def test_dense_chain_hands_the_row_maxima_along(dev, force):
+    """A tower (nn.dense_chain): every large layer's epilogue delivers max |out[r, :]|, the next layer scales by it instead of
+    re-reading its input.  The chained result equals the layers applied one by one with the scaled kernel forced (the maxima
+    are the same numbers either way: bit-identical), the maxima equal numpy's, and everything agrees with the fp64 oracle."""
+    from recamd import nn, ops
+    rng = np.random.default_rng(79)
+    M, widths = 1500, [96, 128, 64, 160, 8]
+    x = rng.normal(size=(M, widths[0])).astype(np.float32)
+    layers = []
+    for i in range(1, len(widths)):
+        d = nn.Dense(widths[i], activation='relu' if i < len(widths) - 1 else None)
+        d.build(widths[i - 1])
+        d.set_weights({"kernel": (rng.normal(size=(widths[i - 1], widths[i])) / np.sqrt(widths[i - 1])).astype(np.float32),
+                       "bias": rng.normal(size=widths[i]).astype(np.float32) * 0.1})
+        layers.append(d)
+    tx = torch.from_numpy(x).to(dev)
+    y1, am = ops.dense(tx, layers[0]._w["kernel"], layers[0]._w["bias"], "relu", want_absmax=True)
+    assert np.array_equal(am.cpu().numpy(), np.abs(y1.cpu().numpy()).max(axis=1))
+    force("dense_pipe", "h")                      # the scaled kernel for every layer, with or without maxima handed over
+    chained_h = nn.dense_chain(layers, tx).cpu().numpy()
+    y1h, amh = ops.dense(tx, layers[0]._w["kernel"], layers[0]._w["bias"], "relu", want_absmax=True)
+    assert np.array_equal(amh.cpu().numpy(), np.abs(y1h.cpu().numpy()).max(axis=1))      # from the epilogue's atomics
+    h = tx
+    for d in layers:
+        h = d(h)
+    assert np.array_equal(chained_h, h.cpu().numpy())
+    force("dense_pipe", None)
+    chained = nn.dense_chain(layers, tx).cpu().numpy()     # default dispatch: the first layer has no maxima and N < 384
+    e = x.astype(np.float64)
+    for i, d in enumerate(layers):
+        w = d.get_weights()
+        e = e @ w["kernel"].astype(np.float64) + w["bias"]
+        if i < len(layers) - 1:
+            e = np.maximum(e, 0)
+    assert close(chained, e, 1e-5) and close(chained_h, e, 1e-5)
