@@ -187,16 +187,14 @@ int rec_dense_prep_f32(const float* x, int64_t x_stride, const float* W, const v
  * other kernels (csrc/dense_f16x2.hip) — instead of the six bf16 MFMAs of the bf16x3 kernels.  absmax_valid != 0: the caller
  * (a producer kernel) already wrote max_k |x[r][k]| into row_absmax; otherwise one pass over x fills it — which pays from
  * N = 384, narrower layers keep the bf16x3 kernels unless the maxima are valid.  out_absmax (optional, M floats): receives
- * max_c |out[r][c]|, i.e. the row_absmax of a layer that consumes `out` (filled by whichever kernel answers).  row_absmax
- * NULL, a shape the kernel does not cover, or prepared weights that rec_dense_f16x2_usable reports as 0: rec_dense_prep_f32.
+ * max_c |out[r][c]|, i.e. the row_absmax of a layer that consumes `out` (filled by whichever kernel answers; the caller
+ * ZEROES it first: the epilogue accumulates with atomic maxima).  row_absmax NULL or a shape the kernel does not cover:
+ * rec_dense_prep_f32.  Non-finite inputs poison their own row, non-finite weights their own column.
  * Same reference call sites as rec_dense_f32. */
 int rec_dense_prep_rs_f32(const float* x, int64_t x_stride, const float* W, const void* prepared,
                           const float* bias, const float* alpha, int32_t act, int64_t M, int32_t K, int32_t N,
                           float* out, int64_t out_stride, float* row_absmax, int32_t absmax_valid, float* out_absmax,
                           void* stream);
-/* *usable = 1 when every column maximum of the prepared W lies within 2^+-40 and all weights are finite (the f16x2 form
- * holds them), else 0: pass row_absmax = NULL for such weights.  Synchronises the stream (one word to the host). */
-int rec_dense_f16x2_usable(const void* prepared, int32_t K, int32_t N, int32_t* usable, void* stream);
 
 /* ---- a7 / K6: ctr MultiHeadAttention (AutoInt interacting layer) ----------------------------
  * src/ctr/layers/modules.py:285-325.  q = act(Xq Wq), k = act(Xk Wk), v = act(Xv Wv) (no bias),

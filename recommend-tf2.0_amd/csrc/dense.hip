@@ -457,7 +457,7 @@ extern "C" int rec_dense_prep_f32(const float* x, int64_t x_stride, const float*
 }
 
 // rec_dense_prep_f32 with one float of workspace per row: large layers whose shape the f16x2 kernel covers (aligned x rows,
-// K % 32 == 0, prepared weights reported usable) run on it — three f16 MFMAs per product instead of six bf16 ones, same
+// K % 32 == 0, prepared weights) run on it — three f16 MFMAs per product instead of six bf16 ones, same
 // accuracy (csrc/dense_f16x2.hip); everything else is rec_dense_prep_f32.  The pass over x that finds the row maxima costs
 // 4 M K bytes of reading against ~a quarter of the GEMM's time saved: it pays from N = 384 (measured: 65 536 x 3456 x 128 is
 // 28 % slower with it, x 1024 27 % faster), so narrower layers take the kernel only when their producer delivered the maxima
@@ -488,19 +488,4 @@ extern "C" int rec_dense_prep_rs_f32(const float* x, int64_t x_stride, const flo
     REC_CHECK_LAUNCH(who);
   }
   return rc;
-}
-
-// 1 when the prepared weights can serve the f16x2 kernel (every column maximum within 2^+-40, all weights finite), else 0.
-// Copies one word to the host and waits for the stream: call it once per prepared buffer.
-extern "C" int rec_dense_f16x2_usable(const void* prepared, int32_t K, int32_t N, int32_t* usable, void* stream) {
-  const char* who = "rec_dense_f16x2_usable";
-  REC_CHECK_ARG(prepared && usable && K >= 1 && N >= 1, REC_EINVAL, "%s: bad argument", who);
-  const int64_t K8 = (int64_t)((K + 15) / 16) * 2, Np = (N + 127) / 128 * 128;
-  const char* flag = static_cast<const char*>(prepared) + dense_b3_prepared_bytes(K, N) + K8 * 2 * Np * 16 + Np * 4;
-  uint32_t v = 0;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  REC_CHECK_ARG(hipMemcpyAsync(&v, flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess,
-                REC_EINVAL, "%s: copy failed", who);
-  *usable = v == 1u ? 1 : 0;
-  return REC_OK;
 }

@@ -7,14 +7,15 @@
 // (h h, h l, l h; l l is 2^-22 of the result) — but only five exponent bits.  The range is bought with EXACT power-of-two
 // scales: every row of x is scaled so that its largest magnitude lies in [2^14, 2^15), every column of W likewise (once, at
 // prepare time), and the result is scaled back in the epilogue:
-//     out[r][c] = act( (sum_k xs[r][k] ws[k][c]) * 2^-ex[r] * 2^-ew[c] + b[c] ),   xs = x 2^ex[r] = xh + xl (+ <= 2^-22 |xs|)
+//     out[r][c] = act( ldexp(sum_k xs[r][k] ws[k][c], -(ex[r] + ew[c])) + b[c] ),   xs = x 2^ex[r] = xh + xl (+ <= 2^-22 |xs|)
 // Powers of two change no mantissa bit, so the scheme's only errors are the dropped l l term and the residual of the
 // two-term split (both <= 2^-22 relative to |x||w| per product, round-to-nearest: unbiased) on top of the fp32
 // accumulation every kernel here has.  Measured against fp64 it is as accurate as the fmaf chain and the bf16x3 kernels or
 // better (their splits truncate): tests/test_dense_gpu.py.  Elements more than 2^-18 below their row's maximum lose their
-// low term to f16's subnormal range: an absolute error below 2^-40 of that maximum.  Rows whose maximum is 0, subnormal,
-// below 2^-95 or non-finite are not scaled (inf / NaN go through the MFMAs and poison exactly their own row); weights whose
-// column maxima leave 2^+-40 make the prepared form unusable and the bf16x3 kernels take over.
+// low term to f16's subnormal range: an absolute error below 2^-40 of that maximum.  Rows whose maximum is 0, subnormal
+// or non-finite are not scaled (inf / NaN go through the MFMAs and poison exactly their own row / column).  The
+// epilogue scales back with ONE v_ldexp_f32 by the sum of the two integer exponents: no intermediate that could overflow
+// where the result does not.
 //
 // Kernel structure = the hand-counted pipeline of csrc/dense_bf16x3.hip: 128 x 128 tile, four waves, W planes global -> LDS
 // by LDS-DMA one k-step ahead, x a whole 128-B line per row and round, scalar bases + 32-bit lane offsets, counted
@@ -33,16 +34,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace h2 {
 constexpr int BM = 128, BN = 128, BK = 16;
 
-// 2^e scale that brings a magnitude with biased exponent `be` into [2^14, 2^15), and its inverse; no scaling (1, 1) for
-// zero / subnormal / tiny (< 2^-95) / non-finite maxima
-__device__ __forceinline__ void scales_of(float absmax, float& s, float& rs) {
+// the exponent e of the power-of-two scale that brings a magnitude into [2^14, 2^15) (applied with v_ldexp_f32: any normal
+// maximum is covered, 2^e itself need not be representable); 0 = no scaling for zero / subnormal / non-finite maxima
+__device__ __forceinline__ int scale_exp(float absmax) {
   const uint32_t be = (__builtin_bit_cast(uint32_t, absmax) >> 23) & 0xffu;
-  if (be < 32u || be == 255u) {
-    s = 1.f, rs = 1.f;
-    return;
-  }
-  s = __builtin_bit_cast(float, (268u - be) << 23);   // 2^(14 - (be - 127))
-  rs = __builtin_bit_cast(float, (be - 14u) << 23);   // 2^((be - 127) - 14)
+  return (be == 0u || be == 255u) ? 0 : 141 - (int)be;      // 14 - (be - 127)
 }
 
 // eight scaled fp32 values -> the f16 fragments of their two terms (round to nearest)
@@ -80,40 +76,39 @@ __global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict
 }
 
 // prepared form: [ceil(K/16)*2][2 planes][Np] f16x8 fragments of W 2^ew[c] (8 consecutive k of one column each), then Np
-// inverse column scales 2^-ew[c], then one flag word (1 = usable).  One thread per column.
+// column exponents ew[c] (int32).  Three small kernels: column maxima (atomic max of the magnitudes' bit patterns over
+// 64-row chunks), the split, and maxima -> exponents.
+__global__ __launch_bounds__(256) void dense_f16x2_colmax_kernel(const float* __restrict__ W, int K, int N,
+                                                                 unsigned int* __restrict__ cmax) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int k0 = blockIdx.y * 64, k1 = k0 + 64 < K ? k0 + 64 : K;
+  float m = 0.f;
+  for (int k = k0; k < k1; ++k) m = fmaxf(m, fabsf(W[(int64_t)k * N + n]));
+  atomicMax(cmax + n, __builtin_bit_cast(unsigned int, m));
+}
 __global__ __launch_bounds__(256) void dense_f16x2_prepare_kernel(const float* __restrict__ W, int K, int N, int Np, int K8,
-                                                                  u32x4* __restrict__ Wq) {
+                                                                  u32x4* __restrict__ Wq, const unsigned int* __restrict__ cmax) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)K8 * Np) return;
+  const int k8 = (int)(t / Np), n = (int)(t - (int64_t)k8 * Np);
+  const int e = h2::scale_exp(__builtin_bit_cast(float, cmax[n]));
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kk = k8 * 8 + j;
+    w[j] = (n < N && kk < K) ? ldexpf(W[(int64_t)kk * N + n], e) : 0.f;
+  }
+  u32x4 h, l;
+  h2::split8(w, h, l);
+  Wq[((int64_t)k8 * 2 + 0) * Np + n] = h;
+  Wq[((int64_t)k8 * 2 + 1) * Np + n] = l;
+}
+__global__ __launch_bounds__(256) void dense_f16x2_colexp_kernel(int Np, unsigned int* __restrict__ cmax_to_exp) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= Np) return;
-  float* rsw = reinterpret_cast<float*>(Wq + (int64_t)K8 * 2 * Np);
-  uint32_t* flag = reinterpret_cast<uint32_t*>(rsw + Np);
-  float m = 0.f;
-  bool bad = false;
-  if (n < N)
-    for (int k = 0; k < K; ++k) {
-      const float w = W[(int64_t)k * N + n];
-      m = fmaxf(m, fabsf(w));
-      bad = bad || !(fabsf(w) <= 3.0e38f);     // inf / NaN weights: not for this kernel
-    }
-  float s, rs;
-  h2::scales_of(m, s, rs);
-  const uint32_t be = (__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu;
-  if (n < N && (bad || (m != 0.f && (be < 127u - 40u || be > 127u + 40u)))) atomicAnd(flag, 0u);
-  rsw[n] = rs;
-  for (int k8 = 0; k8 < K8; ++k8) {
-    float w[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kk = k8 * 8 + j;
-      w[j] = (n < N && kk < K) ? W[(int64_t)kk * N + n] * s : 0.f;
-    }
-    u32x4 h, l;
-    h2::split8(w, h, l);
-    Wq[((int64_t)k8 * 2 + 0) * Np + n] = h;
-    Wq[((int64_t)k8 * 2 + 1) * Np + n] = l;
-  }
+  cmax_to_exp[n] = (unsigned int)h2::scale_exp(__builtin_bit_cast(float, cmax_to_exp[n]));
 }
-__global__ void dense_f16x2_flag_kernel(uint32_t* flag) { *flag = 1u; }
 
 namespace {
 __device__ __forceinline__ void gl16s(u32x4& dst, uint32_t voff, const void* sbase, int imm) {
@@ -138,7 +133,7 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
   constexpr int kStageBytes = 2 * 2 * 2 * 2 * 128 * 16, kTileBytes = 4 * 32 * (64 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
   u32x4 (*frag)[2][2][2][128] = reinterpret_cast<u32x4 (*)[2][2][2][128]>(lds_raw);
-  __shared__ float rsx_s[128];              // the tile's inverse row scales (epilogue)
+  __shared__ int ex_s[128];                 // the tile's row exponents (epilogue)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int l32 = lane & 31, half = lane >> 5;
@@ -166,11 +161,10 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
   const int K8 = K / 8;
   const u32x4* wbase = Wq + n0;                                           // + (ks * 2) * 2 * Np per k-step
   const uint32_t woff = (uint32_t)((skh * 2 * Np + srow) * 16);
-  const float* rsw = reinterpret_cast<const float*>(Wq + (int64_t)K8 * 2 * Np);
+  const int* ew = reinterpret_cast<const int*>(Wq + (int64_t)K8 * 2 * Np);
   const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_addr(&frag[0][1][0][skh][srow & 64]));
-  float sx, rsx;
-  scales_of(absmax[gm < M ? gm : m0], sx, rsx);
-  if (skh == 0) rsx_s[srow] = rsx;
+  const int ex = scale_exp(absmax[gm < M ? gm : m0]);
+  if (skh == 0) ex_s[srow] = ex;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -205,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
     float av[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      av[j] = __builtin_bit_cast(float, lo[j] ^ tok) * sx, av[4 + j] = __builtin_bit_cast(float, hi[j] ^ tok) * sx;
+      av[j] = ldexpf(__builtin_bit_cast(float, lo[j] ^ tok), ex), av[4 + j] = ldexpf(__builtin_bit_cast(float, hi[j] ^ tok), ex);
     u32x4 h, l;
     split8(av, h, l);
     frag[st][0][0][skh][srow] = h;
@@ -260,8 +254,8 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
     __syncthreads();
   }
 
-  // epilogue: C[row = (q&3) + 8*(q>>2) + 4*(lane>>5)][col = lane&31], scaled back by 2^-ew[col] here and by 2^-ex[row] after the
-  // transpose (the order keeps the intermediate in range: |acc| <= 2^30 K, 2^-ew in 2^+-55)
+  // epilogue: C[row = (q&3) + 8*(q>>2) + 4*(lane>>5)][col = lane&31]; the accumulators go through the transpose as they are and
+  // are scaled back by 2^-(ex[row] + ew[col]) in one ldexp
   const int col_ok_base = n0 + wn * 64;
   if (out_vec) {
     constexpr int LDO = 64 + 4;
@@ -270,9 +264,8 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float cs = rsw[col_ok_base + j * 32 + l32];      // Np is padded: always in range
 #pragma unroll
-        for (int q = 0; q < 16; ++q) ot[((q & 3) + 8 * (q >> 2) + 4 * half) * LDO + j * 32 + l32] = acc[i][j][q] * cs;
+        for (int q = 0; q < 16; ++q) ot[((q & 3) + 8 * (q >> 2) + 4 * half) * LDO + j * 32 + l32] = acc[i][j][q];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -284,8 +277,13 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
         const int col = col_ok_base + 4 * c4;
         float m4 = 0.f;
         if (row < M && col < N) {
-          const float rs = rsx_s[wm * 64 + i * 32 + rr];
-          rec_f32x4_t v = *reinterpret_cast<const rec_f32x4_t*>(ot + rr * LDO + 4 * c4) * rs;
+          const int er = ex_s[wm * 64 + i * 32 + rr];
+          const int4 ec = *reinterpret_cast<const int4*>(ew + col);      // Np is padded: always in range
+          rec_f32x4_t v = *reinterpret_cast<const rec_f32x4_t*>(ot + rr * LDO + 4 * c4);
+          v.x = ldexpf(v.x, -(er + ec.x));
+          v.y = ldexpf(v.y, -(er + ec.y));
+          v.z = ldexpf(v.z, -(er + ec.z));
+          v.w = ldexpf(v.w, -(er + ec.w));
           const rec_f32x4_t bb = bias ? *reinterpret_cast<const rec_f32x4_t*>(bias + col) : rec_f32x4_t{0.f, 0.f, 0.f, 0.f};
           const rec_f32x4_t al = alpha ? *reinterpret_cast<const rec_f32x4_t*>(alpha + col) : rec_f32x4_t{0.f, 0.f, 0.f, 0.f};
           v.x = act_apply(v.x + bb.x, act, al.x);
@@ -314,14 +312,14 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
     for (int j = 0; j < 2; ++j) {
       const int col = col_ok_base + j * 32 + l32;
       if (col >= N) continue;
-      const float cs = rsw[col];
+      const int ec = ew[col];
       const float bb = bias ? bias[col] : 0.f;
       const float al = alpha ? alpha[col] : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int lr = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
         const int64_t row = m0 + lr;
-        if (row < M) out[row * out_stride + col] = act_apply(acc[i][j][q] * cs * rsx_s[lr] + bb, act, al);
+        if (row < M) out[row * out_stride + col] = act_apply(ldexpf(acc[i][j][q], -(ex_s[lr] + ec)) + bb, act, al);
       }
     }
 }
@@ -330,19 +328,24 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
 
 int64_t dense_f16x2_bytes(int K, int N) {
   const int64_t K8 = (int64_t)((K + 15) / 16) * 2, Np = (N + 127) / 128 * 128;
-  return K8 * 2 * Np * 16 + Np * 4 + 16;
+  return K8 * 2 * Np * 16 + Np * 4;
 }
 
 void dense_f16x2_prepare_launch(const float* W, int K, int N, void* Wq, hipStream_t st) {
   const int K8 = (K + 15) / 16 * 2, Np = (N + 127) / 128 * 128;
-  uint32_t* flag = reinterpret_cast<uint32_t*>(static_cast<char*>(Wq) + (int64_t)K8 * 2 * Np * 16 + (int64_t)Np * 4);
-  hipLaunchKernelGGL(dense_f16x2_flag_kernel, dim3(1), dim3(1), 0, st, flag);
-  hipLaunchKernelGGL(dense_f16x2_prepare_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, W, K, N, Np, K8,
-                     static_cast<u32x4*>(Wq));
+  unsigned int* cexp = reinterpret_cast<unsigned int*>(static_cast<char*>(Wq) + (int64_t)K8 * 2 * Np * 16);
+  (void)hipMemsetAsync(cexp, 0, (size_t)Np * 4, st);
+  hipLaunchKernelGGL(dense_f16x2_colmax_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((K + 63) / 64)), dim3(256), 0, st, W, K,
+                     N, cexp);
+  const int64_t total = (int64_t)K8 * Np;
+  hipLaunchKernelGGL(dense_f16x2_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, K, N, Np, K8,
+                     static_cast<u32x4*>(Wq), cexp);
+  hipLaunchKernelGGL(dense_f16x2_colexp_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, Np, cexp);
 }
 
-// absmax: M floats of workspace, filled here (one pass over x) unless absmax_valid.  out_absmax (optional, M floats): receives
-// max_c |out[r][c]| — the next layer's row maxima — from the epilogue (rows of 16-B aligned outputs) or from a pass over out.
+// absmax: M floats of workspace, filled here (one pass over x) unless absmax_valid.  out_absmax (optional, M floats, ZEROED by
+// the caller): receives max_c |out[r][c]| — the next layer's row maxima — from the epilogue's atomic maxima (rows of 16-B
+// aligned outputs) or from a pass over out.
 // Returns false when the shape is not covered.
 void row_absmax_launch(const float* x, int64_t x_stride, int64_t M, int K, float* absmax, hipStream_t st) {
   const int vec = (aligned16(x) && x_stride % 4 == 0 && K % 4 == 0) ? 1 : 0;
@@ -363,7 +366,6 @@ bool dense_f16x2_dispatch(const float* x, int64_t x_stride, const void* Wq, cons
   if (!absmax_valid) row_absmax_launch(x, x_stride, M, K, absmax, st);
   const int xcd_map = M >= 4 * (int64_t)N ? 1 : 0;
   const int out_vec = (aligned16(out) && out_stride % 4 == 0 && N % 4 == 0) ? 1 : 0;
-  if (out_absmax && out_vec) (void)hipMemsetAsync(out_absmax, 0, (size_t)M * 4, st);
   hipLaunchKernelGGL(dense_f16x2_pipe_kernel, dim3((unsigned)total), dim3(256), 0, st, x, x_stride, bias, alpha, act, M, K, N,
                      out, out_stride, out_vec, static_cast<const u32x4*>(Wq), Np, xcd_map, absmax, out_vec ? out_absmax : nullptr);
   if (out_absmax && !out_vec) row_absmax_launch(out, out_stride, M, N, out_absmax, st);

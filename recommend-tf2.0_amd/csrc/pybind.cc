@@ -149,11 +149,6 @@ PYBIND11_MODULE(_C, m) {
                                 P<float>(row_absmax), absmax_valid, P<float>(out_absmax), P<void>(stream)),
           "rec_dense_prep_rs_f32");
   });
-  m.def("dense_f16x2_usable", [](ptr_t prepared, int K, int N, ptr_t stream) {
-    int32_t u = 0;
-    check(rec_dense_f16x2_usable(P<const void>(prepared), K, N, &u, P<void>(stream)), "rec_dense_f16x2_usable");
-    return (int)u;
-  });
   m.def("mha_ctr_f32", [](ptr_t xq, ptr_t xk, ptr_t xv, int64_t B, int N, int din, ptr_t Wq,
                           ptr_t Wk, ptr_t Wv, ptr_t W0, int H, int S, int act, ptr_t out,
                           ptr_t stream) {

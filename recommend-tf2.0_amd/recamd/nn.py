@@ -180,22 +180,21 @@ class Dense(Layer):
             self._children["dice"] = self.activation
         self.built = True
 
-    def call(self, x, out=None, row_absmax=None, want_absmax=False, **kwargs):
+    def call(self, x, out=None, row_absmax=None, out_absmax=None, **kwargs):
         if not self.built:
             self.build(x.shape[-1])
         W, b = self._w["kernel"], self._w.get("bias")
-        return self.apply(x, W, b, out=out, row_absmax=row_absmax, want_absmax=want_absmax)
+        return self.apply(x, W, b, out=out, row_absmax=row_absmax, out_absmax=out_absmax)
 
-    def apply(self, x, W, b, out=None, row_absmax=None, want_absmax=False):
-        """row_absmax / want_absmax: the row maxima ops.dense's large-layer kernel scales by, handed from layer to layer
-        (dense_chain) so that no layer re-reads its input to find them; want_absmax returns (out, maxima of out's rows)"""
+    def apply(self, x, W, b, out=None, row_absmax=None, out_absmax=None):
+        """row_absmax / out_absmax: the row maxima ops.dense's large-layer kernel scales by, handed from layer to layer
+        (dense_chain) so that no layer re-reads its input to find them"""
         act = self.activation
         if isinstance(act, PReLU):
-            return ops.dense(x, W, b, "prelu", act._w["alpha"], out=out, row_absmax=row_absmax, want_absmax=want_absmax)
+            return ops.dense(x, W, b, "prelu", act._w["alpha"], out=out, row_absmax=row_absmax, out_absmax=out_absmax)
         if isinstance(act, Dice):
-            y = act(ops.dense(x, W, b, None, out=out, row_absmax=row_absmax))
-            return (y, None) if want_absmax else y
-        return ops.dense(x, W, b, act, out=out, row_absmax=row_absmax, want_absmax=want_absmax)
+            return act(ops.dense(x, W, b, None, out=out, row_absmax=row_absmax))     # Dice rescales: no maxima downstream
+        return ops.dense(x, W, b, act, out=out, row_absmax=row_absmax, out_absmax=out_absmax)
 
 
 def dense_chain(layers, x, out=None, first=None):
@@ -203,17 +202,21 @@ def dense_chain(layers, x, out=None, first=None):
     the row maxima the consumer's kernel scales by (csrc/dense_f16x2.hip).  first: optional (W, b) that replaces the first
     layer's own kernel / bias (a folded BatchNormalization, zero rows for pad columns)."""
     n = len(layers)
-    am = None
+    # layer i hands maxima to layer i + 1 when that one is large: rows >= 1024, K = layer i's width a multiple of 32
+    wants = [i + 1 < n and x.dim() == 2 and x.shape[0] >= 1024 and layers[i].units % 32 == 0 and layers[i].units >= 64
+             and layers[i + 1].units > 8 and not isinstance(layers[i].activation, Dice) for i in range(n)]
+    pool = torch.zeros((sum(wants), x.shape[0]), dtype=torch.float32, device=x.device) if any(wants) else None   # one fill
+    am, slot = None, 0
     for i, layer in enumerate(layers):
         o = out if i == n - 1 else None
-        # the next layer takes the scaled kernel only when it is large: rows >= 1024, K = this layer's width a multiple of 32
-        want = (i + 1 < n and x.shape[0] >= 1024 and x.dim() == 2 and layer.units % 32 == 0 and layer.units >= 64
-                and layers[i + 1].units > 8 and not isinstance(layer.activation, Dice))
+        oam = None
+        if wants[i]:
+            oam, slot = pool[slot], slot + 1
         if i == 0 and first is not None:
-            y = layer.apply(x, first[0], first[1], out=o, row_absmax=am, want_absmax=want)
+            x = layer.apply(x, first[0], first[1], out=o, row_absmax=am, out_absmax=oam)
         else:
-            y = layer(x, out=o, row_absmax=am, want_absmax=want)
-        x, am = y if want else (y, None)
+            x = layer(x, out=o, row_absmax=am, out_absmax=oam)
+        am = oam
     return x
 
 

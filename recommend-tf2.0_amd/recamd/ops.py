@@ -305,28 +305,27 @@ def fm_onehot(dense: torch.Tensor, ids: torch.Tensor, vocab: Sequence[int], w0: 
 _prep_cache = {}
 
 
-def _prepared_weights(W: torch.Tensor):
-    """(prepared buffer, usable by the f16x2 kernel) of a weight matrix, cached per tensor version"""
+def _prepared_weights(W: torch.Tensor) -> torch.Tensor:
+    """the prepared form of a weight matrix (rec_dense_prepare_f32), cached per tensor version"""
     key = id(W)
     ent = _prep_cache.get(key)
     if ent is not None and ent[0]() is W and ent[1] == W._version:
-        return ent[2], ent[3]
+        return ent[2]
     K, N = W.shape
     buf = torch.empty(C.dense_prepared_bytes(K, N), dtype=torch.uint8, device=W.device)
     C.dense_prepare_f32(W.data_ptr(), K, N, buf.data_ptr(), _stream())
-    usable = bool(C.dense_f16x2_usable(buf.data_ptr(), K, N, _stream()))     # one word to the host, once per version
-    _prep_cache[key] = (weakref.ref(W, lambda _r, k=key: _prep_cache.pop(k, None)), W._version, buf, usable)
-    return buf, usable
+    _prep_cache[key] = (weakref.ref(W, lambda _r, k=key: _prep_cache.pop(k, None)), W._version, buf)
+    return buf
 
 
 def dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
           alpha: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-          row_absmax: Optional[torch.Tensor] = None, want_absmax: bool = False):
+          row_absmax: Optional[torch.Tensor] = None, out_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Keras Dense on the last axis: act(x @ W + bias); x (..., K) with unit inner stride.
     Large layers run on the f16x2 kernel (rec_dense_prep_rs_f32), which scales every row of x by a power of two found from
     the row's largest magnitude.  row_absmax: those maxima (M floats), when the kernel that produced x delivered them — a
-    chain of Dense layers passes them along and no layer re-reads its input to find them.  want_absmax: also return the
-    maxima of the OUTPUT rows, as (out, absmax)."""
+    chain of Dense layers passes them along and no layer re-reads its input to find them.  out_absmax: M ZEROED floats that
+    receive the maxima of the output rows (the next layer's row_absmax)."""
     _chk(x, "x")
     _chk(W, "W")
     if W.dim() != 2 or not W.is_contiguous():
@@ -351,22 +350,20 @@ def dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
         _chk(bias, "bias")
     if alpha is not None:
         _chk(alpha, "alpha")
-    prep, usable = _prepared_weights(W) if (M >= 1024 and K * N >= 4096 and not (K <= 64 and N <= 64) and N > 8) else (None, False)
-    out_am = torch.empty(M, dtype=torch.float32, device=x.device) if want_absmax else None
-    if want_absmax or (usable and K % 32 == 0 and xs % 4 == 0 and x2.data_ptr() % 16 == 0):
-        valid = row_absmax is not None and usable
-        if valid:
-            _chk(row_absmax, "row_absmax")
-            if row_absmax.numel() != M or not row_absmax.is_contiguous():
-                raise ValueError("row_absmax: expected M contiguous floats")
-        ws = row_absmax if valid else (torch.empty(M, dtype=torch.float32, device=x.device) if usable else None)
+    for nm, t in (("row_absmax", row_absmax), ("out_absmax", out_absmax)):
+        if t is not None and (_chk(t, nm).numel() != M or not t.is_contiguous()):
+            raise ValueError(f"{nm}: expected M contiguous floats")
+    prep = _prepared_weights(W) if (M >= 1024 and K * N >= 4096 and not (K <= 64 and N <= 64) and N > 8) else None
+    scaled = prep is not None and K % 32 == 0 and xs % 4 == 0 and x2.data_ptr() % 16 == 0
+    if scaled or out_absmax is not None:
+        # one float per row of workspace: the f16x2 kernel (three MFMAs per product) scales every row by its own power of two
+        ws = row_absmax if row_absmax is not None else (torch.empty(M, dtype=torch.float32, device=x.device) if scaled else None)
         C.dense_prep_rs_f32(x2.data_ptr(), xs, W.data_ptr(), _ptr(prep), _ptr(bias), _ptr(alpha), _act_id(act), M, K, N,
-                            out.data_ptr(), out.stride(0), _ptr(ws), 1 if valid else 0, _ptr(out_am), _stream())
+                            out.data_ptr(), out.stride(0), _ptr(ws), 1 if row_absmax is not None else 0, _ptr(out_absmax), _stream())
     else:
         C.dense_prep_f32(x2.data_ptr(), xs, W.data_ptr(), _ptr(prep), _ptr(bias), _ptr(alpha), _act_id(act), M, K, N,
                          out.data_ptr(), out.stride(0), _stream())
-    res = out.view(*lead, N) if out.is_contiguous() and out.shape[1] == N else out
-    return (res, out_am) if want_absmax else res
+    return out.view(*lead, N) if out.is_contiguous() and out.shape[1] == N else out
 
 
 def mha_ctr(xq: torch.Tensor, xk: torch.Tensor, xv: torch.Tensor, Wq, Wk, Wv, W0=None, head_num=1, head_size=None,

@@ -208,22 +208,24 @@ def test_dense_f16x2_ranges(dev, force):
     assert np.all(np.abs(got2 - exp2) <= 2e-6 * scale2 + 1e-30)
 
 
-def test_dense_f16x2_falls_back_for_weights_out_of_range(dev):
-    """a column of W around 2^50: the prepared form reports itself unusable and the bf16x3 kernels answer (still right)"""
+def test_dense_f16x2_extreme_columns_and_rows(dev, force):
+    """one ldexp by the SUM of the row and column exponents scales back: a column of W around 2^100 against rows of x around
+    2^-100 gives its O(1) results (a two-step scale would overflow on the way), and a product beyond fp32's range overflows to
+    inf exactly where fp32 arithmetic does"""
     from recamd import ops
-    from recamd._lib import C
+    force("dense_pipe", "h")
     rng = np.random.default_rng(78)
     M, K, N = 1024, 64, 128
-    x, W, b = _h2_case(rng, M, K, N)
-    W[:, 3] *= np.float32(2.0 ** 50)
-    tw = torch.from_numpy(W).to(dev)
-    prep, usable = ops._prepared_weights(tw)
-    assert not usable
-    got = ops.dense(torch.from_numpy(x).to(dev), tw, torch.from_numpy(b).to(dev)).cpu().numpy()
-    exp = x.astype(np.float64) @ W.astype(np.float64) + b
-    assert close_scaled(got, exp, np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(b))
-    W[:, 3] = rng.normal(size=K).astype(np.float32)
-    assert ops._prepared_weights(torch.from_numpy(W).to(dev))[1]
+    x, W, _ = _h2_case(rng, M, K, N)
+    W[:, 3] *= np.float32(2.0 ** 100)
+    x[10] *= np.float32(2.0 ** -100)
+    x[11] *= np.float32(2.0 ** 100)
+    got = ops.dense(torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev)).cpu().numpy().astype(np.float64)
+    exp = x.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64)
+    fin = np.abs(exp) < 3.0e38
+    assert np.all(np.abs(got[fin] - exp[fin]) <= 2e-6 * scale[fin] + 1e-300)
+    assert 0.01 < abs(exp[10, 3]) < 100 and np.isinf(got[11, 3]) and not fin[11, 3]
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
@@ -270,11 +272,13 @@ def test_dense_chain_hands_the_row_maxima_along(dev, force):
                        "bias": rng.normal(size=widths[i]).astype(np.float32) * 0.1})
         layers.append(d)
     tx = torch.from_numpy(x).to(dev)
-    y1, am = ops.dense(tx, layers[0]._w["kernel"], layers[0]._w["bias"], "relu", want_absmax=True)
+    am = torch.zeros(M, device=dev)
+    y1 = ops.dense(tx, layers[0]._w["kernel"], layers[0]._w["bias"], "relu", out_absmax=am)
     assert np.array_equal(am.cpu().numpy(), np.abs(y1.cpu().numpy()).max(axis=1))
     force("dense_pipe", "h")                      # the scaled kernel for every layer, with or without maxima handed over
     chained_h = nn.dense_chain(layers, tx).cpu().numpy()
-    y1h, amh = ops.dense(tx, layers[0]._w["kernel"], layers[0]._w["bias"], "relu", want_absmax=True)
+    amh = torch.zeros(M, device=dev)
+    y1h = ops.dense(tx, layers[0]._w["kernel"], layers[0]._w["bias"], "relu", out_absmax=amh)
     assert np.array_equal(amh.cpu().numpy(), np.abs(y1h.cpu().numpy()).max(axis=1))      # from the epilogue's atomics
     h = tx
     for d in layers:
