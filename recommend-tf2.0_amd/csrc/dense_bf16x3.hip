@@ -773,9 +773,10 @@ __global__ __launch_bounds__(256, 2) void dense_bf16x3_pipe_deep_kernel(const fl
 
 // W -> [ceil(K/16)*2][3 planes][Np = round_up(N, 128)] bf16x8 fragments (8 consecutive k of one column each)
 __global__ __launch_bounds__(256) void dense_prepare_kernel(const float* __restrict__ W, int K, int N, int Np, int K8,
-                                                            u32x4* __restrict__ Wp) {
+                                                            u32x4* __restrict__ Wp, unsigned int* __restrict__ clear) {
   using namespace b3;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < Np) clear[e] = 0u;        // the f16x2 form's column maxima accumulate by atomic max in the launch that follows
   if (e >= (int64_t)K8 * Np) return;
   const int k8 = (int)(e / Np), n = (int)(e - (int64_t)k8 * Np);
   float w[8];
@@ -872,9 +873,10 @@ int64_t dense_prepared_bytes(int K, int N) { return dense_b3_prepared_bytes(K, N
 void dense_prepare_launch(const float* W, int K, int N, void* Wp, hipStream_t st) {
   const int K8 = (K + 15) / 16 * 2, Np = (N + 127) / 128 * 128;
   const int64_t total = (int64_t)K8 * Np;
+  char* hq = static_cast<char*>(Wp) + dense_b3_prepared_bytes(K, N);
   hipLaunchKernelGGL(dense_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, K, N, Np, K8,
-                     static_cast<u32x4*>(Wp));
-  dense_f16x2_prepare_launch(W, K, N, static_cast<char*>(Wp) + dense_b3_prepared_bytes(K, N), st);
+                     static_cast<u32x4*>(Wp), reinterpret_cast<unsigned int*>(hq + (int64_t)K8 * 2 * Np * 16));
+  dense_f16x2_prepare_launch(W, K, N, hq, st);
 }
 
 }  // namespace rec

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict
 }
 
 // prepared form: [ceil(K/16)*2][2 planes][Np] f16x8 fragments of W 2^ew[c] (8 consecutive k of one column each), then Np
-// column exponents ew[c] (int32).  Three small kernels: column maxima (atomic max of the magnitudes' bit patterns over
-// 64-row chunks), the split, and maxima -> exponents.
+// column maxima (the bit patterns of max_k |W[k][c]|; the kernels derive the exponent).  Two small kernels: column maxima (atomic
+// max over 64-row chunks; the area is zeroed by the bf16x3 prepare kernel that runs first), then the split.
 __global__ __launch_bounds__(256) void dense_f16x2_colmax_kernel(const float* __restrict__ W, int K, int N,
                                                                  unsigned int* __restrict__ cmax) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -104,12 +104,6 @@ __global__ __launch_bounds__(256) void dense_f16x2_prepare_kernel(const float* _
   Wq[((int64_t)k8 * 2 + 0) * Np + n] = h;
   Wq[((int64_t)k8 * 2 + 1) * Np + n] = l;
 }
-__global__ __launch_bounds__(256) void dense_f16x2_colexp_kernel(int Np, unsigned int* __restrict__ cmax_to_exp) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= Np) return;
-  cmax_to_exp[n] = (unsigned int)h2::scale_exp(__builtin_bit_cast(float, cmax_to_exp[n]));
-}
-
 namespace {
 __device__ __forceinline__ void gl16s(u32x4& dst, uint32_t voff, const void* sbase, int imm) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory");
@@ -161,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
   const int K8 = K / 8;
   const u32x4* wbase = Wq + n0;                                           // + (ks * 2) * 2 * Np per k-step
   const uint32_t woff = (uint32_t)((skh * 2 * Np + srow) * 16);
-  const int* ew = reinterpret_cast<const int*>(Wq + (int64_t)K8 * 2 * Np);
+  const float* cmaxw = reinterpret_cast<const float*>(Wq + (int64_t)K8 * 2 * Np);
   const uint32_t wlds = __builtin_amdgcn_readfirstlane(lds_addr(&frag[0][1][0][skh][srow & 64]));
   const int ex = scale_exp(absmax[gm < M ? gm : m0]);
   if (skh == 0) ex_s[srow] = ex;
@@ -278,12 +272,12 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
         float m4 = 0.f;
         if (row < M && col < N) {
           const int er = ex_s[wm * 64 + i * 32 + rr];
-          const int4 ec = *reinterpret_cast<const int4*>(ew + col);      // Np is padded: always in range
+          const rec_f32x4_t cm = *reinterpret_cast<const rec_f32x4_t*>(cmaxw + col);      // Np is padded: always in range
           rec_f32x4_t v = *reinterpret_cast<const rec_f32x4_t*>(ot + rr * LDO + 4 * c4);
-          v.x = ldexpf(v.x, -(er + ec.x));
-          v.y = ldexpf(v.y, -(er + ec.y));
-          v.z = ldexpf(v.z, -(er + ec.z));
-          v.w = ldexpf(v.w, -(er + ec.w));
+          v.x = ldexpf(v.x, -(er + scale_exp(cm.x)));
+          v.y = ldexpf(v.y, -(er + scale_exp(cm.y)));
+          v.z = ldexpf(v.z, -(er + scale_exp(cm.z)));
+          v.w = ldexpf(v.w, -(er + scale_exp(cm.w)));
           const rec_f32x4_t bb = bias ? *reinterpret_cast<const rec_f32x4_t*>(bias + col) : rec_f32x4_t{0.f, 0.f, 0.f, 0.f};
           const rec_f32x4_t al = alpha ? *reinterpret_cast<const rec_f32x4_t*>(alpha + col) : rec_f32x4_t{0.f, 0.f, 0.f, 0.f};
           v.x = act_apply(v.x + bb.x, act, al.x);
@@ -312,7 +306,7 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
     for (int j = 0; j < 2; ++j) {
       const int col = col_ok_base + j * 32 + l32;
       if (col >= N) continue;
-      const int ec = ew[col];
+      const int ec = scale_exp(cmaxw[col]);
       const float bb = bias ? bias[col] : 0.f;
       const float al = alpha ? alpha[col] : 0.f;
 #pragma unroll
@@ -331,16 +325,15 @@ int64_t dense_f16x2_bytes(int K, int N) {
   return K8 * 2 * Np * 16 + Np * 4;
 }
 
+// the column-maxima area must be zero when this runs (dense_prepare_launch: the bf16x3 prepare kernel clears it)
 void dense_f16x2_prepare_launch(const float* W, int K, int N, void* Wq, hipStream_t st) {
   const int K8 = (K + 15) / 16 * 2, Np = (N + 127) / 128 * 128;
-  unsigned int* cexp = reinterpret_cast<unsigned int*>(static_cast<char*>(Wq) + (int64_t)K8 * 2 * Np * 16);
-  (void)hipMemsetAsync(cexp, 0, (size_t)Np * 4, st);
+  unsigned int* cmax = reinterpret_cast<unsigned int*>(static_cast<char*>(Wq) + (int64_t)K8 * 2 * Np * 16);
   hipLaunchKernelGGL(dense_f16x2_colmax_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((K + 63) / 64)), dim3(256), 0, st, W, K,
-                     N, cexp);
+                     N, cmax);
   const int64_t total = (int64_t)K8 * Np;
   hipLaunchKernelGGL(dense_f16x2_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, K, N, Np, K8,
-                     static_cast<u32x4*>(Wq), cexp);
-  hipLaunchKernelGGL(dense_f16x2_colexp_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, Np, cexp);
+                     static_cast<u32x4*>(Wq), cmax);
 }
 
 // absmax: M floats of workspace, filled here (one pass over x) unless absmax_valid.  out_absmax (optional, M floats, ZEROED by
