@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...);
 
 // Kernel selection is by SHAPE only: the library reads no environment variable.  Tests and A/B scripts can force a
 // variant with rec_debug_force(key, value) (include/recamd.h: process-global, not for production); forced(key) is the
-// forced value, or NULL.  Keys: "dense" b|f|s|t, "dense_pipe" 0|s|d, "mha" f|v, "mha_ctr" b, "din" l|s, "cross" l,
+// forced value, or NULL.  Keys: "dense" b|f|s|t, "dense_pipe" 0|s|d|h, "mha" f|v, "mha_ctr" b, "din" l|s, "cross" l,
 // "cross_bpc" n, "pairdot" v, "topk" f, "autoint_wg" n.
 const char* forced(const char* key);
 

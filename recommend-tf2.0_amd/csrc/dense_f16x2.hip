@@ -317,6 +317,12 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
       }
     }
 }
+
+// Round 3 also built this kernel with a 256 x 128 workgroup tile (each wave 128 x 64: 12 fragment reads and one barrier per 24
+// MFMAs instead of 8 and one per 12; a thread staging a whole 128-B x line; 221 VGPRs, two workgroups per CU; text in
+// tools/exp/dense_variants/dense_f16x2_wide.hip.txt).  Bit-identical, and slower where it matters: 65 536 x 1024 x 512
+// 0.274 vs 0.258 ms, x 1024 x 1024 0.534 vs 0.487; 2 - 3 % ahead only for K >= 2048 (profiles/r03_dense_f16x2_wide_ab.txt) —
+// four resident workgroups per CU hide this kernel's serial parts better than larger tiles shrink them.
 #undef REC_HWAIT_X2
 #undef REC_HTOKEN_X2
 
