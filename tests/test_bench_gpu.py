@@ -43,7 +43,12 @@ def test_default_line_carries_every_config(dev):
         assert c["roofline"]["bound"] == bound and 0.05 < c["roofline"]["frac"] < 1.0
         assert c["launch_us"]["p10"] <= c["launch_us"]["p50"] <= c["launch_us"]["p90"]
     assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["cores"] >= 1
+    assert res["cpu_baseline"]["torch_ops"]["value"] > 0
     assert "error" not in res["pcie_inclusive"]
+    mf = res["model_forward"]                                              # the whole DLRM model on the headline's tables
+    assert "error" not in mf, mf
+    assert mf["batch"] == 65536 and res["ms_per_step"] < mf["ms_per_forward"] < 20 * res["ms_per_step"]
+    assert 0.02 < mf["sparse_stage_share"] < 1.0
 
 
 def test_plain_gpus2_command_self_launches_and_reports_both_placements(dev):
