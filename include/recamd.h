@@ -94,6 +94,12 @@ int rec_gather_concat_f32(const rec_table_desc* tables, int32_t F,
 int rec_gather_dots_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
                         int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
                         float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag, void* stream);
+/* The same, also delivering row_absmax[b] = max |element| of sample b's gathered row (B floats, may be NULL) for
+ * rec_dense_prep_rs_f32: the DNN that consumes emb_out (src/ctr/dcn/model.py:53) then needs no pass over it. */
+int rec_gather_dots_absmax_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                               int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
+                               float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag,
+                               float* row_absmax, void* stream);
 int rec_dcn_logit_f32(const float* dots, int32_t L, const float* G, float c, const float* extra, int64_t B,
                       float* out, void* stream);
 
@@ -141,6 +147,13 @@ int rec_gather_fm_f32(const rec_table_desc* tables, int32_t F, const void* ids, 
                       int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
                       const float* w, int64_t B, float* emb_out, int64_t emb_stride, float* fm_out,
                       float* workspace, int32_t* oob_flag, void* stream);
+/* The same, also delivering row_absmax[b] = max |element| of sample b's dense block and gathered rows (B floats, may be
+ * NULL): the row maxima rec_dense_prep_rs_f32 scales by, so that the DNN's first layer (src/ctr/deep_fm/model.py:61) takes
+ * the f16x2 kernel without a pass over the concat buffer. */
+int rec_gather_fm_absmax_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                             int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
+                             const float* w, int64_t B, float* emb_out, int64_t emb_stride, float* fm_out,
+                             float* workspace, int32_t* oob_flag, float* row_absmax, void* stream);
 
 /* ---- a4 / K4: DCN CrossNetwork, src/ctr/layers/modules.py:105-112 --------------------------
  * x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,  l = 0..L-1;  x: (B, dim), w,b: (L, dim) */

@@ -98,6 +98,19 @@ PYBIND11_MODULE(_C, m) {
                 "rec_gather_fm_f32");
         });
 
+  m.def("gather_fm_absmax_f32",
+        [](const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, int64_t ids_stride, ptr_t dense,
+           int64_t dense_stride, int nd, ptr_t w, int64_t B, ptr_t emb_out, int64_t emb_stride, ptr_t fm_out,
+           ptr_t ws, ptr_t oob, ptr_t row_absmax, ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_fm_absmax_f32(d.data(), (int32_t)d.size(), P<const void>(ids), ids_dtype, ids_stride,
+                                         P<const float>(dense), dense_stride, nd, P<const float>(w), B,
+                                         P<float>(emb_out), emb_stride, P<float>(fm_out), P<float>(ws),
+                                         P<int32_t>(oob), P<float>(row_absmax), P<void>(stream)),
+                "rec_gather_fm_absmax_f32");
+        });
+
   m.def("cross_f32", [](ptr_t x, int64_t x_stride, int dim, ptr_t w, ptr_t b, int L, int64_t B,
                         ptr_t out, int64_t out_stride, ptr_t stream) {
     py::gil_scoped_release nogil;
@@ -238,6 +251,17 @@ PYBIND11_MODULE(_C, m) {
                                     P<const float>(Wd), nv, width, B, P<float>(emb_out), emb_stride,
                                     P<float>(out_dots), P<int32_t>(oob), P<void>(stream)),
                 "rec_gather_dots_f32");
+        });
+  m.def("gather_dots_absmax_f32",
+        [](const std::vector<TableTuple>& tables, ptr_t ids, int ids_dtype, int64_t ids_stride, ptr_t Wd, int nv,
+           int width, int64_t B, ptr_t emb_out, int64_t emb_stride, ptr_t out_dots, ptr_t oob, ptr_t row_absmax,
+           ptr_t stream) {
+          auto d = to_descs(tables);
+          py::gil_scoped_release nogil;
+          check(rec_gather_dots_absmax_f32(d.data(), (int32_t)d.size(), P<const void>(ids), ids_dtype, ids_stride,
+                                           P<const float>(Wd), nv, width, B, P<float>(emb_out), emb_stride,
+                                           P<float>(out_dots), P<int32_t>(oob), P<float>(row_absmax), P<void>(stream)),
+                "rec_gather_dots_absmax_f32");
         });
   m.def("dcn_logit_f32", [](ptr_t dots, int L, ptr_t G, float c, ptr_t extra, int64_t B, ptr_t out, ptr_t stream) {
     py::gil_scoped_release nogil;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(TableSet ts, const void*
                                                         int nd, const float* __restrict__ w, int64_t B,
                                                         float* __restrict__ emb_out, int64_t emb_stride,
                                                         float* __restrict__ fm_out, double* __restrict__ partial,
-                                                        int* __restrict__ oob) {
+                                                        int* __restrict__ oob, float* __restrict__ row_absmax) {
   constexpr int D = LPR * 4;
   constexpr int SPW = 64 / LPR;
   __shared__ double wsum[4];
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(TableSet ts, const void*
   const bool live = b_raw < B;
   const int64_t b = live ? b_raw : B - 1;
   double s = 0.0, q = 0.0, lin = 0.0;
+  float amax = 0.f;      // max |element| of the sample's concat row: the scale the DNN's first Dense (f16x2 kernel) needs
   constexpr int U = 8;
   for (int f0 = 0; f0 < F; f0 += U) {
     f32x4 v[U];
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(TableSet ts, const void*
         const int oc = ts.out_col[f] + sl * 4;
         if (live) *reinterpret_cast<f32x4*>(emb_out + b * emb_stride + oc) = v[u];
         const f32x4 wv4 = *reinterpret_cast<const f32x4*>(w + nd + f * D + sl * 4);  // host checks nd % 4 == 0
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
         s += (double)v[u].x + (double)v[u].y + (double)v[u].z + (double)v[u].w;
         q = fma((double)v[u].x, (double)v[u].x, q);
         q = fma((double)v[u].y, (double)v[u].y, q);
@@ -156,13 +158,19 @@ __global__ __launch_bounds__(256) void gather_fm_kernel(TableSet ts, const void*
     }
   }
   // dense part of the first-order term: lanes of the group stride over the nd dense columns
-  for (int d0 = sl; d0 < nd; d0 += LPR) lin = fma((double)dense[b * dense_stride + d0], (double)w[d0], lin);
+  for (int d0 = sl; d0 < nd; d0 += LPR) {
+    const float dv = dense[b * dense_stride + d0];
+    lin = fma((double)dv, (double)w[d0], lin);
+    amax = fmaxf(amax, fabsf(dv));
+  }
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) {
     s += __shfl_xor(s, o, 64);
     q += __shfl_xor(q, o, 64);
+    amax = fmaxf(amax, __shfl_xor(amax, o, 64));
   }
   if (live && sl == 0) fm_out[b] = (float)(0.5 * (s * s - q));
+  if (row_absmax && live && sl == 0) row_absmax[b] = amax;
   double lin_w = live ? lin : 0.0;
   lin_w = wave_sum_f64(lin_w);
   if (lane == 0) wsum[wv] = lin_w;
@@ -536,7 +544,8 @@ template <int LPR, int IDS_F32, int NV>
 __global__ __launch_bounds__(256) void gather_dots_kernel(TableSet ts, const void* __restrict__ ids, int64_t ids_stride,
                                                           int F, const float* __restrict__ Wd, int width, int64_t B,
                                                           float* __restrict__ emb_out, int64_t emb_stride,
-                                                          float* __restrict__ out_dots, int* __restrict__ oob) {
+                                                          float* __restrict__ out_dots, int* __restrict__ oob,
+                                                          float* __restrict__ row_absmax) {
   constexpr int D = LPR * 4;
   constexpr int SPW = 64 / LPR;
   extern __shared__ __attribute__((aligned(16))) float wsh[];  // [NV][width]
@@ -552,6 +561,7 @@ __global__ __launch_bounds__(256) void gather_dots_kernel(TableSet ts, const voi
   float acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+  float amax = 0.f;      // max |element| of the sample's concat row (the DNN's first Dense scales by it: f16x2 kernel)
   constexpr int U = 8;
   for (int f0 = 0; f0 < F; f0 += U) {
     f32x4 r[U];
@@ -570,6 +580,7 @@ __global__ __launch_bounds__(256) void gather_dots_kernel(TableSet ts, const voi
       if (f < F) {
         const int oc = ts.out_col[f] + sl * 4;
         if (live) __builtin_nontemporal_store(r[u], reinterpret_cast<f32x4*>(emb_out + b * emb_stride + oc));
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(r[u].x), fabsf(r[u].y)), fmaxf(fabsf(r[u].z), fabsf(r[u].w))));
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsh + v * width + oc);
@@ -577,6 +588,11 @@ __global__ __launch_bounds__(256) void gather_dots_kernel(TableSet ts, const voi
         }
       }
     }
+  }
+  if (row_absmax) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (live && sl == 0) row_absmax[b] = amax;
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -883,10 +899,22 @@ extern "C" int rec_fm_layer_f32(const float* first, int64_t first_stride, int32_
 
 namespace rec { int fill_table_set(const rec_table_desc* tables, int32_t F, TableSet* ts, const char* who); }
 
+extern "C" int rec_gather_fm_absmax_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                                        int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
+                                        const float* w, int64_t B, float* emb_out, int64_t emb_stride, float* fm_out,
+                                        float* workspace, int32_t* oob_flag, float* row_absmax, void* stream);
 extern "C" int rec_gather_fm_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
                                  int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
                                  const float* w, int64_t B, float* emb_out, int64_t emb_stride,
                                  float* fm_out, float* workspace, int32_t* oob_flag, void* stream) {
+  return rec_gather_fm_absmax_f32(tables, F, ids, ids_dtype, ids_stride, dense, dense_stride, nd, w, B, emb_out, emb_stride,
+                                  fm_out, workspace, oob_flag, nullptr, stream);
+}
+
+extern "C" int rec_gather_fm_absmax_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                                        int64_t ids_stride, const float* dense, int64_t dense_stride, int32_t nd,
+                                        const float* w, int64_t B, float* emb_out, int64_t emb_stride, float* fm_out,
+                                        float* workspace, int32_t* oob_flag, float* row_absmax, void* stream) {
   const char* who = "rec_gather_fm_f32";
   TableSet ts;
   int rc = fill_table_set(tables, F, &ts, who);
@@ -915,10 +943,10 @@ extern "C" int rec_gather_fm_f32(const rec_table_desc* tables, int32_t F, const 
   case L_:                                                                                                 \
     if (ids_dtype == REC_IDS_F32)                                                                          \
       hipLaunchKernelGGL((gather_fm_kernel<L_, 1>), dim3((unsigned)blocks), dim3(256), 0, st, ts, ids, ids_stride, \
-                         F, dense, dense_stride, nd, w, B, emb_out, emb_stride, fm_out, partial, oob_flag); \
+                         F, dense, dense_stride, nd, w, B, emb_out, emb_stride, fm_out, partial, oob_flag, row_absmax); \
     else                                                                                                   \
       hipLaunchKernelGGL((gather_fm_kernel<L_, 0>), dim3((unsigned)blocks), dim3(256), 0, st, ts, ids, ids_stride, \
-                         F, dense, dense_stride, nd, w, B, emb_out, emb_stride, fm_out, partial, oob_flag); \
+                         F, dense, dense_stride, nd, w, B, emb_out, emb_stride, fm_out, partial, oob_flag, row_absmax); \
     break;
   switch (lpr) { REC_GFM(1) REC_GFM(2) REC_GFM(4) REC_GFM(8) REC_GFM(16) REC_GFM(32) REC_GFM(64) }
 #undef REC_GFM
@@ -1074,10 +1102,22 @@ extern "C" int rec_gather_dot_scores_f32(const float* seq_info, int64_t seq_stri
   return REC_OK;
 }
 
+extern "C" int rec_gather_dots_absmax_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                                          int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
+                                          float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag,
+                                          float* row_absmax, void* stream);
 extern "C" int rec_gather_dots_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
                                    int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
                                    float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag,
                                    void* stream) {
+  return rec_gather_dots_absmax_f32(tables, F, ids, ids_dtype, ids_stride, Wd, nv, width, B, emb_out, emb_stride, out_dots,
+                                    oob_flag, nullptr, stream);
+}
+
+extern "C" int rec_gather_dots_absmax_f32(const rec_table_desc* tables, int32_t F, const void* ids, int32_t ids_dtype,
+                                          int64_t ids_stride, const float* Wd, int32_t nv, int32_t width, int64_t B,
+                                          float* emb_out, int64_t emb_stride, float* out_dots, int32_t* oob_flag,
+                                          float* row_absmax, void* stream) {
   const char* who = "rec_gather_dots_f32";
   TableSet ts;
   int rc = fill_table_set(tables, F, &ts, who);
@@ -1108,7 +1148,7 @@ extern "C" int rec_gather_dots_f32(const rec_table_desc* tables, int32_t F, cons
   REC_CHECK_ARG(blocks <= 0x7fffffffLL, REC_ESHAPE, "%s: batch too large", who);
 #define REC_GD3(L_, I_, V_)                                                                                       \
   hipLaunchKernelGGL((gather_dots_kernel<L_, I_, V_>), dim3((unsigned)blocks), dim3(256), lds, st, ts, ids, ids_stride, \
-                     F, Wd, width, B, emb_out, emb_stride, out_dots, oob_flag)
+                     F, Wd, width, B, emb_out, emb_stride, out_dots, oob_flag, row_absmax)
 #define REC_GD2(L_, I_)                                                            \
   switch (nv) {                                                                    \
     case 1: REC_GD3(L_, I_, 1); break;                                             \

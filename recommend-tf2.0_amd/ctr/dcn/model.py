@@ -60,8 +60,10 @@ class DCN(Model):
             # output meets nothing but the final Dense(1) (:55-56), so neither x_l nor the concat is materialised:
             # the dots ride along with the gather, the logit is alpha_L (x0 . w_c) + const + dnn_x . w_d.
             Wd, G, c, w_d = self._cross_constants(dim)
-            x, dots = ops.gather_dots(self._group, sparse_inputs, Wd)        # :47 + :51 (+ the cross half of :56)
-            dnn_part = ops.dense(self.dnn_network(x), w_d)                   # :53 + the dnn half of :56
+            B = sparse_inputs.shape[0]
+            am = torch.empty(B, dtype=torch.float32, device=self.device) if B >= 1024 else None   # row maxima for the DNN
+            x, dots = ops.gather_dots(self._group, sparse_inputs, Wd, row_absmax=am)   # :47 + :51 (+ the cross half of :56)
+            dnn_part = ops.dense(self.dnn_network(x, row_absmax=am), w_d)    # :53 + the dnn half of :56
             return ops.dcn_logit(dots, G, c, dnn_part)
         return self._call_unfused(sparse_inputs)
 

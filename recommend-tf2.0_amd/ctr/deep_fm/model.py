@@ -46,6 +46,7 @@ class DeepFM(Model):
         self._w_pad = None
 
     def call(self, inputs, **kwargs):
+        am = None
         dense_inputs, sparse_inputs = inputs
         dense_inputs = to_device_f32(dense_inputs, self.device)
         sparse_inputs = to_device_ids(sparse_inputs, self.device)
@@ -65,11 +66,13 @@ class DeepFM(Model):
                 wp = torch.zeros(self.pad + self.feature_length, dtype=torch.float32, device=self.device)
                 wp[self.pad:] = self.fm._w['w'].reshape(-1)
                 self._w_pad = (key, wp)
+            # the same pass also delivers every row's largest magnitude: the DNN's first Dense scales by it (f16x2 kernel)
+            am = torch.empty(B, dtype=torch.float32, device=self.device) if B >= 1024 else None
             fm_outputs = ops.gather_fm(self._group, sparse_inputs, buf[:, :self.pad + self.nd], self._w_pad[1],
-                                       self.pad + self.nd, buf)               # :53 + :59
+                                       self.pad + self.nd, buf, row_absmax=am)   # :53 + :59
         else:
             ops.gather_concat(self._group, sparse_inputs, out=buf)              # :53 (sparse part)
             fm_outputs = self.fm([embeds, sparse_embed])                       # :59
         # the DNN reads the whole 16-B aligned buffer, zeroed pad columns included (zero rows in its folded kernel)
-        deep_outputs = self.dense(self.dnn(buf, lead_pad=self.pad, tail_pad=self.tail))                    # :61-62
+        deep_outputs = self.dense(self.dnn(buf, lead_pad=self.pad, tail_pad=self.tail, row_absmax=am))      # :61-62
         return ops.add_sigmoid(fm_outputs, deep_outputs)                       # :64

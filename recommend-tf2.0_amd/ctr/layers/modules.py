@@ -68,7 +68,7 @@ class DNN(nn.Layer):
         self.dropout = nn.Dropout(dnn_dropout)
         self._folded = None
 
-    def call(self, inputs, out=None, lead_pad=0, tail_pad=0, **kwargs):
+    def call(self, inputs, out=None, lead_pad=0, tail_pad=0, row_absmax=None, **kwargs):
         """lead_pad / tail_pad > 0: `inputs` carries that many extra ZERO columns in front of / behind the features (a
         16-B aligned view of a concat buffer; the zero pad column of a row stride rounded up to 4 floats); the folded
         first-layer kernel gets as many zero rows, so the product is unchanged and the GEMM stays on its aligned path
@@ -83,7 +83,7 @@ class DNN(nn.Layer):
                 z = lambda r: torch.zeros((r, Wf.shape[1]), dtype=Wf.dtype, device=Wf.device)  # noqa: E731
                 Wf = torch.cat([z(lead_pad), Wf, z(tail_pad)], dim=0).contiguous()
             self._folded = (key, (Wf, bf))
-        x = nn.dense_chain(self.dnn_network, inputs, out=out, first=self._folded[1])
+        x = nn.dense_chain(self.dnn_network, inputs, out=out, first=self._folded[1], row_absmax=row_absmax)
         return self.dropout(x)
 
 

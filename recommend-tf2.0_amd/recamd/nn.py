@@ -197,16 +197,17 @@ class Dense(Layer):
         return ops.dense(x, W, b, act, out=out, row_absmax=row_absmax, out_absmax=out_absmax)
 
 
-def dense_chain(layers, x, out=None, first=None):
+def dense_chain(layers, x, out=None, first=None, row_absmax=None):
     """x -> layers[0] -> layers[1] -> ... (a tower's Dense stack).  Between two large layers the producer's epilogue delivers
     the row maxima the consumer's kernel scales by (csrc/dense_f16x2.hip).  first: optional (W, b) that replaces the first
-    layer's own kernel / bias (a folded BatchNormalization, zero rows for pad columns)."""
+    layer's own kernel / bias (a folded BatchNormalization, zero rows for pad columns).  row_absmax: the maxima of x's rows
+    when the kernel that produced x delivered them."""
     n = len(layers)
     # layer i hands maxima to layer i + 1 when that one is large: rows >= 1024, K = layer i's width a multiple of 32
     wants = [i + 1 < n and x.dim() == 2 and x.shape[0] >= 1024 and layers[i].units % 32 == 0 and layers[i].units >= 64
              and layers[i + 1].units > 8 and not isinstance(layers[i].activation, Dice) for i in range(n)]
     pool = torch.zeros((sum(wants), x.shape[0]), dtype=torch.float32, device=x.device) if any(wants) else None   # one fill
-    am, slot = None, 0
+    am, slot = row_absmax, 0
     for i, layer in enumerate(layers):
         o = out if i == n - 1 else None
         oam = None

@@ -632,7 +632,7 @@ def unpermute_rows(rows: torch.Tensor, perm: torch.Tensor, out: Optional[torch.T
 
 
 def gather_dots(group: TableGroup, ids: torch.Tensor, Wd: torch.Tensor, out: Optional[torch.Tensor] = None,
-                oob_flag: Optional[torch.Tensor] = None):
+                oob_flag: Optional[torch.Tensor] = None, row_absmax: Optional[torch.Tensor] = None):
     """gather_concat + dots[b, v] = <concat row b, Wd[v]> for up to 8 weight vectors Wd (nv, width), in one pass.
     Returns (concat rows (B, >= group.width), dots (B, nv))."""
     ids = _rows2d(_chk(ids, "ids", None), "ids")
@@ -645,8 +645,9 @@ def gather_dots(group: TableGroup, ids: torch.Tensor, Wd: torch.Tensor, out: Opt
     if out is None:
         out = torch.empty((B, (group.width + 3) // 4 * 4), dtype=torch.float32, device=ids.device)[:, :group.width]
     dots = torch.empty((B, nv), dtype=torch.float32, device=ids.device)
-    C.gather_dots_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0), Wd.data_ptr(), nv, width, B,
-                      out.data_ptr(), out.stride(0), dots.data_ptr(), _ptr(oob_flag), _stream())
+    # row_absmax (B floats): also receive max |element| of every gathered row (ops.dense's row_absmax)
+    C.gather_dots_absmax_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0), Wd.data_ptr(), nv, width, B,
+                             out.data_ptr(), out.stride(0), dots.data_ptr(), _ptr(oob_flag), _ptr(row_absmax), _stream())
     return out, dots
 
 
@@ -808,7 +809,7 @@ def gather_din_attention_pool(q, group: TableGroup, ids, mask, W, bias, act="sig
 
 
 def gather_fm(group: TableGroup, ids: torch.Tensor, dense: Optional[torch.Tensor], w_padded: torch.Tensor, nd_padded: int,
-              emb_out: torch.Tensor, oob_flag=None) -> torch.Tensor:
+              emb_out: torch.Tensor, oob_flag=None, row_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused K1+K3 (DeepFM): gathers into the concat buffer `emb_out` (group.out_cols) and returns the FM
     layer output (B,1) computed in the same pass.  `dense` is the (B, nd_padded) dense block AS STORED in
     the concat buffer (zero-padded to a multiple of 4 columns), `w_padded` = FM weights in the same
@@ -819,9 +820,10 @@ def gather_fm(group: TableGroup, ids: torch.Tensor, dense: Optional[torch.Tensor
     w_padded = _chk(w_padded, "w").reshape(-1)
     fm_out = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
     ws = _fm_workspace(ids.device, B)
-    C.gather_fm_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0), _ptr(dense),
-                    dense.stride(0) if dense is not None else 0, nd_padded, w_padded.data_ptr(), B, emb_out.data_ptr(),
-                    emb_out.stride(0), fm_out.data_ptr(), ws.data_ptr(), _ptr(oob_flag), _stream())
+    # row_absmax (B floats): also receive max |element| of every sample's concat row (ops.dense's row_absmax)
+    C.gather_fm_absmax_f32(group.descs, ids.data_ptr(), _ids_dtype(ids), ids.stride(0), _ptr(dense),
+                           dense.stride(0) if dense is not None else 0, nd_padded, w_padded.data_ptr(), B, emb_out.data_ptr(),
+                           emb_out.stride(0), fm_out.data_ptr(), ws.data_ptr(), _ptr(oob_flag), _ptr(row_absmax), _stream())
     return fm_out
 
 

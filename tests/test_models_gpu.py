@@ -59,7 +59,7 @@ def test_fm_model_config1(dev):
     assert close(out, ref.fm_model_onehot(dense, ids, vocabs, w['w0'], w['w'], w['V']))
 
 
-@pytest.mark.parametrize("D,B", [(8, 300), (5, 64)])
+@pytest.mark.parametrize("D,B", [(8, 300), (5, 64), (16, 2048)])      # 2048 rows: the DNN takes the row maxima from the gather
 def test_deepfm(dev, D, B):
     from ctr.deep_fm.model import DeepFM
     rng = np.random.default_rng(D)
@@ -74,12 +74,13 @@ def test_deepfm(dev, D, B):
     assert close(out, exp)
 
 
-def test_dcn(dev):
+@pytest.mark.parametrize("B,D", [(200, 8), (2048, 16)])      # 2048 rows: the DNN takes the row maxima from the gather
+def test_dcn(dev, B, D):
     from ctr.dcn.model import DCN
     rng = np.random.default_rng(4)
     vocabs = [int(v) for v in rng.integers(3, 200, size=26)]
-    m = DCN(sparse_cols(vocabs, 8), hidden_units=[32, 16, 8])
-    _, ids = inputs(rng, 200, vocabs, 0)
+    m = DCN(sparse_cols(vocabs, D), hidden_units=[32, 16, 8])
+    _, ids = inputs(rng, B, vocabs, 0)
     m(ids)
     w = randomize(m, rng, 0.05)
     out = m(ids).cpu().numpy()

@@ -147,11 +147,15 @@ def test_gather_fm_fused(dev, B, F, D, nd):
     buf[:, pad:pad + nd] = T(dense, dev)
     wp = np.zeros(pad + nd + F * D, np.float32)
     wp[pad:] = w[:, 0]
-    out = ops.gather_fm(g, T(ids, dev), buf[:, :pad + nd], T(wp, dev), pad + nd, buf).cpu().numpy()
+    am = torch.full((B,), -1.0, device=dev)
+    out = ops.gather_fm(g, T(ids, dev), buf[:, :pad + nd], T(wp, dev), pad + nd, buf, row_absmax=am).cpu().numpy()
     emb = ref.gather_concat(tables, ids, oob="zero")
     assert np.array_equal(buf[:, pad + nd:].cpu().numpy(), emb)
     first = np.concatenate([dense, emb], axis=1)
     assert close(out, ref.fm_layer(first, emb, w))
+    # the same pass delivers every concat row's largest magnitude (the first Dense's row scale): exact
+    assert np.array_equal(am.cpu().numpy(), np.abs(buf.cpu().numpy()).max(axis=1))
+    assert np.array_equal(out, ops.gather_fm(g, T(ids, dev), buf[:, :pad + nd], T(wp, dev), pad + nd, buf).cpu().numpy())
 
 
 @pytest.mark.parametrize("B,F,D,nv", [(1, 3, 8, 1), (300, 26, 16, 4), (129, 5, 128, 8), (64, 26, 128, 4)])
@@ -167,9 +171,11 @@ def test_gather_dots_and_dcn_logit(dev, B, F, D, nv):
     Wd = (rng.normal(size=(nv, dim)) / np.sqrt(dim)).astype(np.float32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     g = ops.TableGroup([t(x) for x in tables])
-    x, dots = ops.gather_dots(g, t(ids), t(Wd))
+    am = torch.full((B,), -1.0, device=dev)
+    x, dots = ops.gather_dots(g, t(ids), t(Wd), row_absmax=am)
     ex = ref.gather_concat([a.astype(np.float64) for a in tables], ids)
     assert np.array_equal(x.cpu().numpy(), ex.astype(np.float32))
+    assert np.array_equal(am.cpu().numpy(), np.abs(ex.astype(np.float32)).max(axis=1))     # the rows' largest magnitudes
     assert close(dots.cpu().numpy(), ex @ Wd.astype(np.float64).T)
     # DCN logit: L = nv - 1 cross layers, last vector = the cross half of the final Dense(1)
     L = nv - 1
