@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256, 3) void dense_f16x2_pipe_kernel(const float* _
 // MFMAs instead of 8 and one per 12; a thread staging a whole 128-B x line; 221 VGPRs, two workgroups per CU; text in
 // tools/exp/dense_variants/dense_f16x2_wide.hip.txt).  Bit-identical, and slower where it matters: 65 536 x 1024 x 512
 // 0.274 vs 0.258 ms, x 1024 x 1024 0.534 vs 0.487; 2 - 3 % ahead only for K >= 2048 (profiles/r03_dense_f16x2_wide_ab.txt) —
-// four resident workgroups per CU hide this kernel's serial parts better than larger tiles shrink them.
+// four resident workgroups per CU hide this kernel's serial parts better than larger tiles shrink them.  The same holds for
+// the register-prefetched ("deep") form of the bf16x3 file applied here (170 VGPRs, two workgroups per CU; text in
+// tools/exp/dense_variants/dense_f16x2_deep.hip.txt): bit-identical, 0.312 vs 0.261 ms at 1024 x 512, behind at every shape but
+// 65 536 x 3456 x 128 (profiles/r03_dense_f16x2_deep_ab.txt).
 #undef REC_HWAIT_X2
 #undef REC_HTOKEN_X2
 
