@@ -293,3 +293,44 @@ def test_dense_chain_hands_the_row_maxima_along(dev, force):
         if i < len(layers) - 1:
             e = np.maximum(e, 0)
     assert close(chained, e, 1e-5) and close(chained_h, e, 1e-5)
+
+
+@pytest.mark.parametrize("case", ["all_positive", "cancelling", "heavy_tailed", "relu_sparse"])
+def test_dense_f16x2_error_against_the_magnitude_it_summed(dev, force, case):
+    """The f16x2 kernel's a-priori bound: per product it drops l_x l_w and the residual of the two-term split, each
+    <= 2^-22 |x||w| (round to nearest), and accumulates in fp32 like every kernel here — so |err| <= c * sum_k |x||w| with c a
+    small multiple of 2^-22 ~ 2.4e-7 from the split, plus the fp32 accumulation every kernel shares.  Worst-case style inputs: all-positive operands at
+    K = 4096 (nothing cancels in the error), rows that cancel to ~0 (the error stays relative to what was summed, not to the
+    result), log-normal magnitudes, and relu-sparse activations.  The fp32-MFMA kernel (an fmaf chain) is held to the same bound
+    and the f16x2 error may not exceed twice its error."""
+    from recamd import ops
+    rng = np.random.default_rng({"all_positive": 1, "cancelling": 2, "heavy_tailed": 3, "relu_sparse": 4}[case])
+    M, K, N = 1024, 4096, 128
+    if case == "all_positive":
+        x, W = rng.random((M, K)).astype(np.float32), rng.random((K, N)).astype(np.float32)
+    elif case == "cancelling":
+        h = rng.normal(size=(M, K // 2)).astype(np.float32)
+        x = np.concatenate([h, -h], axis=1)
+        w = rng.normal(size=(K // 2, N)).astype(np.float32)
+        W = np.concatenate([w, w * np.float32(1 + 2.0 ** -12)], axis=0)       # x W = -2^-12 h w: ~4000 times smaller than its terms
+    elif case == "heavy_tailed":
+        x = (rng.normal(size=(M, K)) * np.exp(rng.normal(size=(M, K)) * 3)).astype(np.float32)
+        W = (rng.normal(size=(K, N)) * np.exp(rng.normal(size=(K, N)) * 2)).astype(np.float32)
+    else:
+        x = np.maximum(rng.normal(size=(M, K)) - 1.0, 0).astype(np.float32)     # ~84 % zeros
+        W = (rng.normal(size=(K, N)) / 64).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    exp = x.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64)
+    force("dense_pipe", "h")
+    got = ops.dense(t(x), t(W)).cpu().numpy().astype(np.float64)
+    force("dense_pipe", None)
+    force("dense", "f")
+    got_f = ops.dense(t(x), t(W)).cpu().numpy().astype(np.float64)
+    ratio = lambda g: float((np.abs(g - exp) / np.maximum(scale, 1e-300)).max())  # noqa: E731
+    r, rf = ratio(got), ratio(got_f)
+    # fp32 accumulation of same-signed terms is the larger part (a-priori K 2^-24 relative to the magnitude summed; measured
+    # 2.4e-6 for f16x2 against 3.7 - 4.1e-6 for the fmaf chain on the all-positive and relu cases): f16x2 stays within the fp32
+    # kernel's error plus its own 2^-22, and both far inside the a-priori bound
+    assert rf <= K * 2.0 ** -24 and r <= K * 2.0 ** -24, (r, rf)
+    assert r <= 1.5 * rf + 2.4e-7, (r, rf)
