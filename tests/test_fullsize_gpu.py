@@ -90,3 +90,39 @@ def test_full_fused_dot_properties(world, dev):
     Xd = torch.cat([ops.gather_concat(g, ids[:1024]).view(1024, F, D), dense[:1024, None, :]], dim=1).contiguous()
     assert close_dot(ops.pairwise_dot(Xd).cpu().numpy(), Xd.cpu().numpy())
     assert close_dot(out[:1024, :P].cpu().numpy(), Xd.cpu().numpy())
+
+
+def test_full_dlrm_model_forward_sampled_vs_oracle(world, dev, force):
+    """The whole DLRM model (src/ctr/dlrm/model.py:42-54, dot interaction) on the configs[1] tables at batch 65 536 — what
+    bench.py's `model_forward` times: bottom MLP 13-512-256-128, fused gather + pairwise dot, top MLP 479-1024-1024-512-256-1.
+    Its Dense layers run on the f16x2 kernel with row maxima handed along the towers.  Sampled samples vs the fp64 oracle
+    (the oracle gathers only their rows), the forward is deterministic, and the bf16x3 kernels give the same logits to 1e-5."""
+    from ctr.dlrm.model import DLRM
+    from recamd import ops
+    from tests.test_models_gpu import dense_cols, dnn_params, randomize
+    arena, ids, dense128, g = world
+    nd = 13
+    rng = np.random.default_rng(7)
+    m = DLRM([dense_cols(nd), [{'feat': f'C{i}', 'feat_num': 1, 'embed_dim': D} for i in range(F)]], [512, 256, D],
+             [1024, 1024, 512, 256], interaction='dot')
+    dense = torch.rand((B, nd), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    m([dense[:8], torch.zeros((8, F), dtype=torch.int32, device=dev)])        # lazy build on the one-row tables
+    w = randomize(m, rng, 0.08)
+    for f in range(F):                                                       # then the real tables, as bench.py does
+        layer = m.embed_layers['embed_%d' % f]
+        layer._w["embeddings"], layer.input_dim = arena[f], V
+    m._group = ops.TableGroup([m.embed_layers['embed_%d' % f].table for f in range(F)])
+    out = m([dense, ids])
+    assert torch.equal(out, m([dense, ids]))
+    rows = np.random.default_rng(8).integers(0, B, size=64)
+    ids_h = ids[rows].cpu().numpy()
+    # compact tables holding just the sampled rows (row j of table f = the row sample j looks up)
+    tabs = [arena[f][torch.from_numpy(ids_h[:, f]).long().to(dev)].cpu().numpy() for f in range(F)]
+    cid = np.tile(np.arange(len(rows), dtype=np.int32)[:, None], (1, F))
+    exp = ref.dlrm_forward(dense[rows].cpu().numpy(), cid, tabs, dnn_params(w, 'bot_dnn', 3), dnn_params(w, 'top_dnn', 4),
+                           (w['final_dense/kernel'], w['final_dense/bias']), 'dot')
+    got = out[rows].cpu().numpy()
+    assert close(got, exp)
+    force("dense_pipe", "s")                                                 # the six-MFMA scheme on the same model
+    alt = m([dense, ids])[rows].cpu().numpy()
+    assert close(alt, exp) and np.abs(alt - got).max() <= 1e-5
