@@ -60,7 +60,9 @@ constexpr int kU = REC_SASREC_KU;   // row-load instructions per landing buffer 
 // 2 x 4, 3 x 4, 4 x 4 82.9 / 84.9 / 99.1.  More rows in flight per wave do not help: ~33 MB of row requests are outstanding
 // chip-wide, the memory system is saturated for this pattern — touching the candidate rows ahead (LDS-DMA of 4 B per lane
 // into a dead buffer while the matvec chain runs) costs 14 % (r03_sasrec_touch_ab.txt), and a batch with every sample at
-// the mean length is only 6 % faster (r03_sasrec_lens_ab.txt).  (An arm that indexes a landing buffer it does not have
+// the mean length is only 6 % faster (r03_sasrec_lens_ab.txt); compacting the NEXT sample's id list while this sample's
+// candidate rows are in flight (the 9 % of a sample spent there, moved under a memory wait) changes nothing: 83.1 - 86.2 vs
+// 82.9 - 84.8 us (r03_sasrec_early_compact_ab.txt).  (An arm that indexes a landing buffer it does not have
 // compiles, skips that buffer's loads and looks 10 % faster: hence the oracle check per arm.)
 #ifndef REC_SASREC_ATT_BUFS
 #define REC_SASREC_ATT_BUFS 1
