@@ -820,7 +820,19 @@ def whole_model_forward(torch, dev, a, w, steps=30):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"model": "DLRM dot: bottom MLP 13-512-256-128, gather + pairwise dot (26 x 1M x 128 tables), top MLP 479-1024-1024-512-256-1, "
+    # the same forward with every Dense on the fp32-MFMA kernel (an fmaf chain; rec_debug_force is the A/B hook): how far the
+    # 16-bit-matrix-core schemes are from plain fp32 arithmetic on this model's outputs (sigmoid probabilities)
+    from recamd._lib import C
+    sl = slice(0, min(B, 8192))
+    got = m([dense[sl], ids[0][sl]]).reshape(-1)
+    C.debug_force("dense", "f")
+    try:
+        ref32 = m([dense[sl], ids[0][sl]]).reshape(-1)
+    finally:
+        C.debug_force("dense", None)
+    diff = float((got - ref32).abs().max().item())
+    return {"max_abs_diff_vs_fp32_mfma_dense": diff, "compared_samples": int(sl.stop),
+            "model": "DLRM dot: bottom MLP 13-512-256-128, gather + pairwise dot (26 x 1M x 128 tables), top MLP 479-1024-1024-512-256-1, "
                      "sigmoid; fp32 weights and activations, Dense layers on the f16x2 / bf16x3 kernels (fp32-accurate)",
             "batch": B, "steps": steps, "ms_per_forward": round(ms, 4), "value": round(B / ms * 1e3, 1), "unit": "samples/s",
             "sparse_stage_share": round(w.get("headline_ms", 0.0) / ms, 3) if w.get("headline_ms") else None}

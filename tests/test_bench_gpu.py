@@ -49,6 +49,7 @@ def test_default_line_carries_every_config(dev):
     assert "error" not in mf, mf
     assert mf["batch"] == 65536 and res["ms_per_step"] < mf["ms_per_forward"] < 20 * res["ms_per_step"]
     assert 0.02 < mf["sparse_stage_share"] < 1.0
+    assert mf["compared_samples"] == 8192 and mf["max_abs_diff_vs_fp32_mfma_dense"] <= 1e-5      # probabilities: |p| <= 1
 
 
 def test_plain_gpus2_command_self_launches_and_reports_both_placements(dev):
